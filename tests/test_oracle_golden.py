@@ -1,0 +1,94 @@
+"""Pins the CPU oracle against vectors produced by the reference's own
+``batched_fgsm_attack`` + HF ViT (tests/golden/make_golden.py, run in the build
+container).  CPU-only; no HIP involved."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vit_lora_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLD, f"fgsm_{name}.npz"))
+    im, ps, hid, L, H, mlp, C, B, seed = [int(v) for v in z["meta"]]
+    cfg = O.OracleConfig(image_size=im, patch_size=ps, hidden=hid, layers=L, heads=H, mlp=mlp, num_labels=C)
+    w = O.init_weights(cfg, seed=seed, std=0.02 if name == "vitb" else 0.05)
+    assert abs(float(sum(v.double().sum() for v in w.values())) - float(z["weight_sum"])) < 1e-6, \
+        "seeded weights differ from the ones the golden vectors were made with"
+    g = torch.Generator().manual_seed(seed + 1000)
+    x = torch.rand(B, 3, im, im, generator=g)
+    y = torch.randint(0, C, (B,), generator=g)
+    return cfg, w, x, y, z
+
+
+@pytest.mark.parametrize("name", ["tiny17", "tiny197", "vitb"])
+def test_forward_and_input_grad_match_reference(name):
+    cfg, w, x, y, z = load_case(name)
+    loss, g, logits = O.loss_and_input_grad(w, cfg, x, y)
+    ref_logits = torch.from_numpy(z["logits"])
+    ref_grad = torch.from_numpy(z["grad"])
+    assert torch.allclose(logits, ref_logits, rtol=1e-4, atol=1e-5)
+    assert abs(loss.item() - float(z["loss"])) < 1e-5
+    rel = (g - ref_grad).norm() / ref_grad.norm()
+    assert rel < 1e-4, rel
+
+
+@pytest.mark.parametrize("name", ["tiny17", "tiny197", "vitb"])
+def test_fgsm_matches_reference_function(name):
+    cfg, w, x, y, z = load_case(name)
+    eps = float(z["eps"])
+    adv = O.fgsm(w, cfg, x, y, eps)
+    sign = torch.sign(adv - x).to(torch.int8)
+    ref_sign = torch.from_numpy(z["adv_minus_x_sign"])
+    # sign() of a float gradient: fp32 re-association may flip a vanishing fraction
+    agree = (sign == ref_sign).float().mean().item()
+    assert agree > 0.9995, agree
+    assert abs((adv - x).abs().max().item() - float(z["adv_absmax"])) < 1e-7
+    assert abs(adv.double().sum().item() - float(z["adv_sum"])) < 2 * eps * 0.0005 * adv.numel() + 1e-3
+
+
+def test_lora_param_count_known_answers():
+    """infLora.ipynb:163 and :919 (r=4 / r=16 on query,value; 101 classes)."""
+    cfg = O.OracleConfig(num_labels=101)
+    l4 = O.OracleLora(r=4, targets=O.resolve_targets(["query", "value"]))
+    assert O.count_parameters(cfg, l4) == (225_125, 86_101_450)
+    l16 = O.OracleLora(r=16, targets=O.resolve_targets(["query", "value"]))
+    assert O.count_parameters(cfg, l16) == (667_493, 86_543_818)
+
+
+def test_target_resolution_like_peft():
+    # train_loras.py:81 -> q, k, v, attention out-proj AND mlp fc2 (suffix match)
+    assert O.resolve_targets(["query", "key", "value", "output.dense"]) == ("q", "k", "v", "o", "fc2")
+    assert O.resolve_targets(["dense"]) == ("o", "fc1", "fc2")
+    cfg = O.OracleConfig()
+    l8 = O.OracleLora(r=8, targets=O.resolve_targets(["query", "key", "value", "output.dense"]))
+    tr, _ = O.count_parameters(cfg, l8)
+    assert tr - (768 * 21 + 21) == 958_464
+
+
+def test_pgd_step_and_quantisation():
+    x0 = torch.tensor([0.0, 0.5, 1.0, 0.5, 0.02])
+    adv = torch.tensor([0.0, 0.52, 1.0, 0.47, 0.0])
+    g = torch.tensor([-1.0, 2.0, 3.0, 0.0, -0.1])
+    out = O.pgd_step(adv, x0, g, eps=0.03, alpha=0.02)
+    assert torch.allclose(out, torch.tensor([0.0, 0.53, 1.0, 0.47, 0.0]))
+    q = O.save_images_quant(torch.tensor([[[[0.999, 1.2]], [[-0.1, 0.5]], [[0.0039, 0.0039215]]]]))
+    assert q.flatten().tolist() == [254, 0, 0, 255, 127, 0]
+
+
+def test_adam_matches_torch_optim():
+    torch.manual_seed(0)
+    p0 = torch.randn(1000)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([p], lr=1e-4)
+    q, m, v = p0.clone(), torch.zeros(1000), torch.zeros(1000)
+    for t in range(1, 4):
+        g = torch.randn(1000)
+        p.grad = g.clone()
+        opt.step()
+        q, m, v = O.adam_step(q, g, m, v, t)
+    assert torch.allclose(q, p.detach(), rtol=1e-6, atol=1e-7)
