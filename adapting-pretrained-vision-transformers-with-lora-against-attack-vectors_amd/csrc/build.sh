@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build libvitlora_hip.so for gfx950 (cross-compiles without a GPU).
+set -e
+cd "$(dirname "$0")"
+OUT=../libvitlora_hip.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+mkdir -p build
+pids=()
+for f in gemm elementwise attention lora_grad vitlora; do
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ kernels.h -nt build/$f.o ] || [ gemm.h -nt build/$f.o ] || [ ../../include/vitlora.h -nt build/$f.o ]; then
+    hipcc $FLAGS -c $f.hip -o build/$f.o &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT build/gemm.o build/elementwise.o build/attention.o build/lora_grad.o build/vitlora.o
+echo "built $OUT"

@@ -1,0 +1,493 @@
+// HBM-bound kernels of the path: patch gather (+normalise), LayerNorm fwd/bwd, the CLS
+// head with cross-entropy, the fused FGSM/PGD update (K10), the PGD random start (K11),
+// flat Adam (K12), the save_images quantiser and the weight packers.
+// Every kernel moves 16 bytes per lane wherever the layout allows it.
+#include "kernels.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------
+// K1+K2 gather: pixels [B,3,S,S] f32 -> patches [B*NP (padded), 3*P*P] bf16, (x-mean)/std fused
+// (whitebox_attacks.py:26 feeds (perturbed-mean)/std to the Conv2d patch projection).
+// ---------------------------------------------------------------------------------
+__global__ void patch_gather_kernel(const float* __restrict__ x, bf16* __restrict__ out, int B, int S,
+                                    int P, int G, int normalise, float m0, float m1, float m2,
+                                    float is0, float is1, float is2) {
+    const int K = 3 * P * P;
+    const int64_t total = (int64_t)B * G * G * (K / 8);
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(t % (K / 8));
+        const int64_t m = t / (K / 8);
+        const int col = c8 * 8;
+        const int c = col / (P * P), rem = col - c * P * P;
+        const int ph = rem / P, pw = rem - ph * P;
+        const int b = (int)(m / (G * G)), pi = (int)(m - (int64_t)b * G * G);
+        const int py = pi / G, px = pi - py * G;
+        const float* src = x + (((int64_t)b * 3 + c) * S + py * P + ph) * S + px * P + pw;
+        const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
+        float mean = 0.f, is = 1.f;
+        if (normalise) { mean = c == 0 ? m0 : (c == 1 ? m1 : m2); is = c == 0 ? is0 : (c == 1 ? is1 : is2); }
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o[i] = f2bf((v0[i] - mean) * is); o[4 + i] = f2bf((v1[i] - mean) * is); }
+        *(bf16x8*)(out + m * K + col) = o;
+    }
+}
+
+// x[b*T + 0][:] = cls + pos[0]   (ViTEmbeddings: cat(cls, patches) + position_embeddings)
+__global__ void cls_rows_kernel(float* __restrict__ x, const float* __restrict__ cls,
+                                const float* __restrict__ pos, int B, int T, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * D) return;
+    const int b = i / D, d = i - b * D;
+    x[(int64_t)b * T * D + d] = cls[d] + pos[d];
+}
+
+// ---------------------------------------------------------------------------------
+// LayerNorm forward: one wave per row, two-pass statistics in registers.
+// ---------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, bf16* __restrict__ h,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = D >> 2;
+    const float* xr = x + (int64_t)row * D;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        v[i] = c < nv ? *(const f32x4*)(xr + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float d = v[i][k] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    bf16* hr = h + (int64_t)row * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const f32x4 g = *(const f32x4*)(gamma + c * 4), b = *(const f32x4*)(beta + c * 4);
+            bf16x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = f2bf((v[i][k] - mean) * rstd * g[k] + b[k]);
+            *(bf16x4*)(hr + c * 4) = o;
+        }
+    }
+}
+
+// LayerNorm backward fused with the residual-gradient add:
+//   dx = dres + rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dh * gamma
+// writes dx as f32 (residual-gradient stream) and as bf16 (A operand of the next dgrad GEMM).
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restrict__ dh, const float* __restrict__ x,
+                                                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                            const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                            float* __restrict__ dx, bf16* __restrict__ dx_bf, int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = D >> 2;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    const int64_t off = (int64_t)row * D;
+    f32x4 g[NV], xh[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        xh[i] = g[i];
+        if (c < nv) {
+            const bf16x4 d = *(const bf16x4*)(dh + off + c * 4);
+            const f32x4 xv = *(const f32x4*)(x + off + c * 4);
+            const f32x4 gm = *(const f32x4*)(gamma + c * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                g[i][k] = bf2f(d[k]) * gm[k];
+                xh[i][k] = (xv[k] - mean) * rstd;
+                s1 += g[i][k];
+                s2 += g[i][k] * xh[i][k];
+            }
+        }
+    }
+    const float c1 = wave_sum(s1) / D, c2 = wave_sum(s2) / D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const f32x4 r = *(const f32x4*)(dres + off + c * 4);
+            f32x4 o; bf16x4 ob;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o[k] = r[k] + rstd * (g[i][k] - c1 - xh[i][k] * c2);
+                ob[k] = f2bf(o[k]);
+            }
+            *(f32x4*)(dx + off + c * 4) = o;
+            *(bf16x4*)(dx_bf + off + c * 4) = ob;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// CLS head: final LayerNorm on token 0 + classifier (fp32) -- modeling_vit.py:385,560-561.
+// one block (256 threads) per image.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, int T, int D, int C, float eps,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ Wc, const float* __restrict__ bc,
+                                                       float* __restrict__ xhat_out, float* __restrict__ xf_out,
+                                                       float* __restrict__ rstd_out, float* __restrict__ logits) {
+    extern __shared__ float sm[];      // [D] normalised+affine CLS row, then 4 floats of reduction scratch
+    float* xf = sm;
+    float* red = sm + D;
+    const int b = blockIdx.x;
+    const float* xr = x + (int64_t)b * T * D;
+    float s = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) s += xr[d];
+    const float mean = block_sum256(s, red) / D;
+    float q = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) { const float t = xr[d] - mean; q += t * t; }
+    const float rstd = rsqrtf(block_sum256(q, red) / D + eps);
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const float xh = (xr[d] - mean) * rstd;
+        const float v = xh * gamma[d] + beta[d];
+        xf[d] = v;
+        xhat_out[(int64_t)b * D + d] = xh;
+        xf_out[(int64_t)b * D + d] = v;
+    }
+    if (threadIdx.x == 0) rstd_out[b] = rstd;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int c = w; c < C; c += 4) {
+        float a = 0.f;
+        for (int d = lane; d < D; d += 64) a += xf[d] * Wc[(int64_t)c * D + d];
+        a = wave_sum(a);
+        if (lane == 0) logits[(int64_t)b * C + c] = a + bc[c];
+    }
+}
+
+// F.cross_entropy(logits, labels), mean reduction; dlogits = (softmax - onehot)/B.
+// single block; one wave per image, round-robin.
+__global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                      int B, int C, float* __restrict__ dlogits, float* __restrict__ loss_out) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float lsum = 0.f;
+    for (int b = w; b < B; b += 4) {
+        const float* lr = logits + (int64_t)b * C;
+        float mx = -INFINITY;
+        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, lr[c]);
+        mx = wave_max(mx);
+        float se = 0.f;
+        for (int c = lane; c < C; c += 64) se += expf(lr[c] - mx);
+        se = wave_sum(se);
+        const int y = (int)labels[b];
+        const float lse = mx + logf(se);
+        for (int c = lane; c < C; c += 64)
+            dlogits[(int64_t)b * C + c] = (expf(lr[c] - lse) - (c == y ? 1.f : 0.f)) / B;
+        if (lane == 0) lsum += lse - lr[y];
+    }
+    if (lane == 0) red[w] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss_out = (red[0] + red[1] + red[2] + red[3]) / B;
+}
+
+// head backward: d(xf) = dlogits * Wc ; LN backward on the CLS row; writes the CLS row of the
+// residual-gradient stream (all other rows of that stream are zero: memset by the driver).
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ Wc,
+                                                       const float* __restrict__ gamma, const float* __restrict__ xhat,
+                                                       const float* __restrict__ rstd_in, int T, int D, int C,
+                                                       float* __restrict__ dx, bf16* __restrict__ dx_bf) {
+    extern __shared__ float sm[];
+    float* g = sm;           // [D]
+    float* red = sm + D;
+    const int b = blockIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) a += dlogits[(int64_t)b * C + c] * Wc[(int64_t)c * D + d];
+        a *= gamma[d];
+        g[d] = a;
+        s1 += a;
+        s2 += a * xhat[(int64_t)b * D + d];
+    }
+    const float c1 = block_sum256(s1, red) / D;
+    const float c2 = block_sum256(s2, red) / D;
+    const float rstd = rstd_in[b];
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const float o = rstd * (g[d] - c1 - xhat[(int64_t)b * D + d] * c2);
+        dx[(int64_t)b * T * D + d] = o;
+        dx_bf[(int64_t)b * T * D + d] = f2bf(o);
+    }
+}
+
+// classifier gradient (train): dW[c][d] = sum_b dlogits[b][c] * xf[b][d]; db[c] = sum_b dlogits[b][c]
+__global__ void classifier_grad_kernel(const float* __restrict__ dlogits, const float* __restrict__ xf, int B, int D,
+                                       int C, float* __restrict__ dW, float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C * D) {
+        const int c = i / D, d = i - c * D;
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) a += dlogits[(int64_t)b * C + c] * xf[(int64_t)b * D + d];
+        dW[i] = a;
+    }
+    if (i < C) {
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) a += dlogits[(int64_t)b * C + i];
+        db[i] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// K10: fused input-grad -> sign -> eps-project -> clamp.  16 B/elem algorithmic traffic
+// (reads g, adv, x0; writes adv).  whitebox_attacks.py:32-36 (FGSM) / torchattacks PGD step.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float sgn(float g) { return (g > 0.f) ? 1.f : ((g < 0.f) ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(256) void pgd_step_kernel(float* __restrict__ adv, const float* __restrict__ x0,
+                                                       const float* __restrict__ grad, float eps, float alpha,
+                                                       float lo, float hi, int64_t n4, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f32x4 a = *(const f32x4*)(adv + i * 4);
+        const f32x4 x = *(const f32x4*)(x0 + i * 4);
+        const f32x4 g = *(const f32x4*)(grad + i * 4);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t = a[k] + alpha * sgn(g[k]);
+            const float d = fminf(fmaxf(t - x[k], -eps), eps);
+            o[k] = fminf(fmaxf(x[k] + d, lo), hi);
+        }
+        *(f32x4*)(adv + i * 4) = o;
+    }
+    // tail (n not a multiple of 4)
+    const int64_t i = n4 * 4 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float t = adv[i] + alpha * sgn(grad[i]);
+        const float d = fminf(fmaxf(t - x0[i], -eps), eps);
+        adv[i] = fminf(fmaxf(x0[i] + d, lo), hi);
+    }
+}
+
+// K11: counter-based uniform noise (splitmix64 finaliser on (seed, index)); not torch's stream
+// (random_start=True, whitebox_attacks.py:113, needs a seeded deterministic start, not that stream).
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void pgd_init_kernel(float* __restrict__ adv, const float* __restrict__ x0, float eps, float lo, float hi,
+                                uint64_t seed, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t r = mix64(seed * 0xD1342543DE82EF95ull + (uint64_t)i);
+        const float u = (float)(r >> 40) * (1.0f / 16777216.0f);       // [0,1)
+        const float v = x0[i] + (2.f * u - 1.f) * eps;
+        adv[i] = fminf(fmaxf(v, lo), hi);
+    }
+}
+
+// K12: torch.optim.Adam single flat update (train_loras.py:284,315)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, float lr, float b1, float b2, float eps, float bc1,
+                            float sqrt_bc2, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+}
+
+// save_images (Utils.py:108-112): clamp(0,1) -> *255 -> uint8 truncation, CHW -> HWC
+__global__ void quantize_kernel(const float* __restrict__ img, uint8_t* __restrict__ out, int B, int Cn, int H, int W) {
+    const int64_t n = (int64_t)B * Cn * H * W;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // i indexes the OUTPUT (b, y, x, c)
+    const int c = (int)(i % Cn);
+    int64_t r = i / Cn;
+    const int xx = (int)(r % W); r /= W;
+    const int yy = (int)(r % H);
+    const int b = (int)(r / H);
+    float v = img[(((int64_t)b * Cn + c) * H + yy) * W + xx];
+    v = fminf(fmaxf(v, 0.f), 1.f);
+    out[i] = (uint8_t)(v * 255.f);
+}
+
+__global__ void channel_affine_kernel(float* __restrict__ dst, const float* __restrict__ src, float s0, float s1,
+                                      float s2, float t0, float t1, float t2, int64_t hw, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int c = (int)((i / hw) % 3);
+        const float sc = c == 0 ? s0 : (c == 1 ? s1 : s2), sh = c == 0 ? t0 : (c == 1 ? t1 : t2);
+        dst[i] = src[i] * sc + sh;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// packers
+// ---------------------------------------------------------------------------------
+// dst[r*ldd + coff + c] = bf16(scale * src[r*cols + c])
+__global__ void pack_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int rows, int cols, int ldd,
+                                 int coff, float scale) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+    dst[(int64_t)r * ldd + coff + c] = f2bf(scale * src[i]);
+}
+// dst[c*ldd + roff + r] = bf16(scale * src[r*cols + c])   (transpose)
+__global__ void pack_bf16_t_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int rows, int cols, int ldd,
+                                   int roff, float scale) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const int r = by + k, c = bx + tx;
+        tile[k][tx] = (r < rows && c < cols) ? src[(int64_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = bx + k, r = by + tx;
+        if (r < rows && c < cols) dst[(int64_t)c * ldd + roff + r] = f2bf(scale * tile[tx][k]);
+    }
+}
+// W'[o][k] = bf16(W[o][k] + s * sum_j B[o][j] A[j][k])  (merge_and_unload), optionally transposed
+__global__ void merge_lora_kernel(const float* __restrict__ W, const float* __restrict__ A, const float* __restrict__ Bm,
+                                  int out, int in, int r, float s, bf16* __restrict__ dst, int ldd, int roff,
+                                  bf16* __restrict__ dstT, int lddT, int coffT) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)out * in) return;
+    const int o = (int)(i / in), k = (int)(i - (int64_t)o * in);
+    float a = 0.f;
+    for (int j = 0; j < r; ++j) a += Bm[(int64_t)o * r + j] * A[(int64_t)j * in + k];
+    const bf16 v = f2bf(W[i] + s * a);
+    dst[(int64_t)(roff + o) * ldd + k] = v;
+    dstT[(int64_t)k * lddT + coffT + o] = v;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------
+static inline int nblk(int64_t n, int t, int cap = 1 << 20) {
+    int64_t b = (n + t - 1) / t;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+void k_patch_gather(const float* x, bf16* out, int B, int S, int P, int normalise, const float* mean,
+                    const float* std, hipStream_t s) {
+    const int G = S / P;
+    const int64_t total = (int64_t)B * G * G * (3 * P * P / 8);
+    hipLaunchKernelGGL(patch_gather_kernel, dim3(nblk(total, 256, 8192)), dim3(256), 0, s, x, out, B, S, P, G,
+                       normalise, mean[0], mean[1], mean[2], 1.f / std[0], 1.f / std[1], 1.f / std[2]);
+}
+void k_cls_rows(float* x, const float* cls, const float* pos, int B, int T, int D, hipStream_t s) {
+    hipLaunchKernelGGL(cls_rows_kernel, dim3(nblk((int64_t)B * D, 256)), dim3(256), 0, s, x, cls, pos, B, T, D);
+}
+void k_layernorm_fwd(const float* x, bf16* h, float* mean, float* rstd, const float* g, const float* b, int M, int D,
+                     float eps, hipStream_t s) {
+    const int nv = (D / 4 + 63) / 64;
+    dim3 grid((M + 3) / 4), blk(256);
+    switch (nv) {
+        case 1: hipLaunchKernelGGL(layernorm_fwd_kernel<1>, grid, blk, 0, s, x, h, mean, rstd, g, b, M, D, eps); break;
+        case 2: hipLaunchKernelGGL(layernorm_fwd_kernel<2>, grid, blk, 0, s, x, h, mean, rstd, g, b, M, D, eps); break;
+        case 3: hipLaunchKernelGGL(layernorm_fwd_kernel<3>, grid, blk, 0, s, x, h, mean, rstd, g, b, M, D, eps); break;
+        default: hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, blk, 0, s, x, h, mean, rstd, g, b, M, D, eps); break;
+    }
+}
+void k_layernorm_bwd(const bf16* dh, const float* x, const float* mean, const float* rstd, const float* g,
+                     const float* dres, float* dx, bf16* dx_bf, int M, int D, hipStream_t s) {
+    const int nv = (D / 4 + 63) / 64;
+    dim3 grid((M + 3) / 4), blk(256);
+    switch (nv) {
+        case 1: hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, blk, 0, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D); break;
+        case 2: hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, blk, 0, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D); break;
+        case 3: hipLaunchKernelGGL(layernorm_bwd_kernel<3>, grid, blk, 0, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D); break;
+        default: hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, blk, 0, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D); break;
+    }
+}
+void k_head_fwd(const float* x, int B, int T, int D, int C, float eps, const float* g, const float* b, const float* Wc,
+                const float* bc, float* xhat, float* xf, float* rstd, float* logits, hipStream_t s) {
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), (D + 4) * sizeof(float), s, x, T, D, C, eps, g, b, Wc, bc,
+                       xhat, xf, rstd, logits);
+}
+void k_ce_loss(const float* logits, const int64_t* labels, int B, int C, float* dlogits, float* loss, hipStream_t s) {
+    hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(256), 0, s, logits, labels, B, C, dlogits, loss);
+}
+void k_head_bwd(const float* dlogits, const float* Wc, const float* g, const float* xhat, const float* rstd, int B,
+                int T, int D, int C, float* dx, bf16* dx_bf, hipStream_t s) {
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), (D + 4) * sizeof(float), s, dlogits, Wc, g, xhat, rstd, T,
+                       D, C, dx, dx_bf);
+}
+void k_classifier_grad(const float* dlogits, const float* xf, int B, int D, int C, float* dW, float* db, hipStream_t s) {
+    hipLaunchKernelGGL(classifier_grad_kernel, dim3(nblk((int64_t)C * D, 256)), dim3(256), 0, s, dlogits, xf, B, D, C,
+                       dW, db);
+}
+void k_pgd_step(float* adv, const float* x0, const float* grad, float eps, float alpha, float lo, float hi, int64_t n,
+                hipStream_t s) {
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(pgd_step_kernel, dim3(nblk(n4 > 0 ? n4 : 1, 256, 2048)), dim3(256), 0, s, adv, x0, grad, eps,
+                       alpha, lo, hi, n4, n);
+}
+void k_pgd_init(float* adv, const float* x0, float eps, float lo, float hi, uint64_t seed, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(pgd_init_kernel, dim3(nblk(n, 256, 4096)), dim3(256), 0, s, adv, x0, eps, lo, hi, seed, n);
+}
+void k_adam(float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps, int t, int64_t n,
+            hipStream_t s) {
+    const float bc1 = 1.f - powf(b1, (float)t);
+    const float sqrt_bc2 = sqrtf(1.f - powf(b2, (float)t));
+    hipLaunchKernelGGL(adam_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, p, g, m, v, lr, b1, b2, eps, bc1, sqrt_bc2, n);
+}
+void k_channel_affine(float* dst, const float* src, const float* scale, const float* shift, int B, int64_t hw,
+                      hipStream_t s) {
+    const int64_t n = (int64_t)B * 3 * hw;
+    hipLaunchKernelGGL(channel_affine_kernel, dim3(nblk(n, 256, 4096)), dim3(256), 0, s, dst, src, scale[0], scale[1],
+                       scale[2], shift[0], shift[1], shift[2], hw, n);
+}
+void k_quantize(const float* img, uint8_t* out, int B, int C, int H, int W, hipStream_t s) {
+    const int64_t n = (int64_t)B * C * H * W;
+    hipLaunchKernelGGL(quantize_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, img, out, B, C, H, W);
+}
+void k_pack_bf16(const float* src, bf16* dst, int rows, int cols, int ldd, int coff, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(nblk((int64_t)rows * cols, 256)), dim3(256), 0, s, src, dst, rows, cols,
+                       ldd, coff, scale);
+}
+void k_pack_bf16_t(const float* src, bf16* dst, int rows, int cols, int ldd, int roff, float scale, hipStream_t s) {
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+    hipLaunchKernelGGL(pack_bf16_t_kernel, grid, dim3(256), 0, s, src, dst, rows, cols, ldd, roff, scale);
+}
+void k_merge_lora(const float* W, const float* A, const float* B, int out, int in, int r, float sc, bf16* dst, int ldd,
+                  int roff, bf16* dstT, int lddT, int coffT, hipStream_t s) {
+    hipLaunchKernelGGL(merge_lora_kernel, dim3(nblk((int64_t)out * in, 256)), dim3(256), 0, s, W, A, B, out, in, r, sc,
+                       dst, ldd, roff, dstT, lddT, coffT);
+}

@@ -1,0 +1,38 @@
+// GEMM entry points shared between gemm.hip and the model driver.
+#pragma once
+#include "common.h"
+
+// C[M,N] = A1[M,K1] * W1[N,K1]^T + A2[M,K2] * W2[N,K2]^T  (+ epilogue)
+// Both operands are K-contiguous bf16 ("NT" form); the optional second pair is the
+// rank-r LoRA update appended as extra K tiles:  [x | x A^T] * [W | s B]^T.
+enum GemmEpilogue {
+    EPI_STORE_BF16 = 0,   // C(bf16) = acc + bias
+    EPI_RESID_F32 = 1,    // C(f32)  = acc + bias + R(f32)        (R may alias C)
+    EPI_GELU = 2,         // C2(bf16) = z = acc + bias ; C(bf16) = gelu(z)
+    EPI_GELU_BWD = 3,     // C(bf16) = acc * gelu'(R(bf16))
+    EPI_PATCH_FWD = 4,    // C(f32)[row b*T + 1 + p] = acc + bias + pos[1+p]
+    EPI_PATCH_BWD = 5,    // image-layout scatter of d(patches), scaled by 1/std[c]
+    EPI_STORE_F32 = 6,    // C(f32) = acc + bias
+};
+
+struct GemmArgs {
+    const bf16* A1; const bf16* W1; int lda1, ldw1, K1;
+    const bf16* A2; const bf16* W2; int lda2, ldw2, K2;
+    int M;            // rows computed (multiple of 128; buffers are padded to it)
+    int Mvalid;       // rows that may be stored by the remapping epilogues
+    int N;            // multiple of BN
+    const float* bias;
+    void* C; int ldc;
+    void* C2; int ldc2;
+    const void* R; int ldr;
+    // patch epilogues
+    const float* pos; int tokens; int patches; int grid; int psize; int img;
+    float inv_std[3];
+    // A-row gather for the patch-embedding backward: GEMM row m = b*patches + p reads A row
+    // b*tokens + 1 + p (the non-CLS rows of the token-major gradient); 0 = off
+    int a_gather;
+};
+
+// bn = 128 (default) or 64 (skinny LoRA-down GEMMs)
+void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s);
+void gemm_init();   // one-time kernel attributes (outside any stream capture)

@@ -1,0 +1,213 @@
+// bf16 MFMA GEMM for gfx950 with fused epilogues and the LoRA rank-r update appended as
+// extra K tiles.  Stands in for the cuBLAS/MKL matmuls that HF ViT + peft issue on the
+// reference's hot path (whitebox_attacks.py:27, train_loras.py:310; SURVEY.md K2,K4,K6-K8).
+//
+// v1 structure: 128 x BN x 64 tile, 4 waves (2x2), direct-to-LDS 16-byte loads
+// (global_load_lds_dwordx4) into a double-buffered, XOR-swizzled row-major image
+// (rows of 128 B; 16-byte chunk c of row r stored at chunk c ^ (r & 7): conflict-free
+// ds_read_b128 fragment reads), one barrier per K step, 16x16x32 MFMA with the operands
+// swapped so that each lane owns 4 consecutive output columns (8/16-byte stores).
+#include "gemm.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 64;
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, f32x4 v) {
+    if constexpr (EPI == EPI_STORE_BF16) {
+        bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        *(bf16x4*)((bf16*)p.C + (size_t)m * p.ldc + n) = o;
+    } else if constexpr (EPI == EPI_STORE_F32) {
+        *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+    } else if constexpr (EPI == EPI_RESID_F32) {
+        const f32x4 r = *(const f32x4*)((const float*)p.R + (size_t)m * p.ldr + n);
+        *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v + r;
+    } else if constexpr (EPI == EPI_GELU) {
+        bf16x4 z = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        bf16x4 a = {f2bf(gelu_f(v[0])), f2bf(gelu_f(v[1])), f2bf(gelu_f(v[2])), f2bf(gelu_f(v[3]))};
+        *(bf16x4*)((bf16*)p.C2 + (size_t)m * p.ldc2 + n) = z;
+        *(bf16x4*)((bf16*)p.C + (size_t)m * p.ldc + n) = a;
+    } else if constexpr (EPI == EPI_GELU_BWD) {
+        const bf16x4 z = *(const bf16x4*)((const bf16*)p.R + (size_t)m * p.ldr + n);
+        bf16x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = f2bf(v[i] * gelu_grad_f(bf2f(z[i])));
+        *(bf16x4*)((bf16*)p.C + (size_t)m * p.ldc + n) = o;
+    } else if constexpr (EPI == EPI_PATCH_FWD) {
+        if (m < p.Mvalid) {
+            const int b = m / p.patches, pi = m - b * p.patches;
+            const f32x4 pe = *(const f32x4*)(p.pos + (size_t)(1 + pi) * p.ldc + n);
+            *(f32x4*)((float*)p.C + ((size_t)b * p.tokens + 1 + pi) * p.ldc + n) = v + pe;
+        }
+    } else if constexpr (EPI == EPI_PATCH_BWD) {
+        if (m < p.Mvalid) {
+            const int b = m / p.patches, pi = m - b * p.patches;
+            const int py = pi / p.grid, px = pi - py * p.grid;
+            const int pp = p.psize * p.psize;
+            const int c = n / pp, rem = n - c * pp;
+            const int ph = rem / p.psize, pw = rem - ph * p.psize;
+            const float s = p.inv_std[c];
+            f32x4 o = {v[0] * s, v[1] * s, v[2] * s, v[3] * s};
+            float* dst = (float*)p.C + (((size_t)b * 3 + c) * p.img + py * p.psize + ph) * p.img +
+                         px * p.psize + pw;
+            *(f32x4*)dst = o;
+        }
+    }
+}
+
+template <int BN, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* sA = (bf16*)smem;              // [2][BM][BK]
+    bf16* sW = sA + 2 * BM * BK;         // [2][BN][BK]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tilesN = p.N / BN;
+    const int ntiles = (p.M / BM) * tilesN;
+    const int id = xcd_remap(blockIdx.x, ntiles);
+    const int bm = id / tilesN, bn = id - bm * tilesN;
+    const int wm = w >> 1, wn = w & 1;
+    constexpr int NJ = BN / 32;          // 16-wide column tiles per wave
+    constexpr int WG = BN / 32;          // 8-row load groups of the W tile per wave
+
+    f32x4 acc[4][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk1 = p.K1 / BK;
+    const int nk = nk1 + p.K2 / BK;
+    const int lr = lane >> 3;            // row inside an 8-row load group
+    const int lc = lane & 7;             // 16-byte chunk position inside the 128-byte row
+
+    // per-lane A rows of the 4 load groups (fixed over the K loop)
+    size_t arow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = bm * BM + (w * 4 + i) * 8 + lr;
+        if (p.a_gather) m = m < p.Mvalid ? m + m / p.patches + 1 : 0;
+        arow[i] = (size_t)m;
+    }
+
+    auto issue = [&](int kt, int buf) {
+        const bf16* Ap; const bf16* Wp; int lda, ldw, k0;
+        if (kt < nk1) { Ap = p.A1; Wp = p.W1; lda = p.lda1; ldw = p.ldw1; k0 = kt * BK; }
+        else          { Ap = p.A2; Wp = p.W2; lda = p.lda2; ldw = p.ldw2; k0 = (kt - nk1) * BK; }
+        bf16* dA = sA + buf * BM * BK;
+        bf16* dW = sW + buf * BN * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int g = w * 4 + i;
+            const int r = g * 8 + lr;
+            const int c = lc ^ (r & 7);
+            glds16(Ap + arow[i] * lda + k0 + c * 8, dA + g * 8 * BK);
+        }
+#pragma unroll
+        for (int i = 0; i < WG; ++i) {
+            const int g = w * WG + i;
+            const int r = g * 8 + lr;
+            const int c = lc ^ (r & 7);
+            glds16(Wp + (size_t)(bn * BN + r) * ldw + k0 + c * 8, dW + g * 8 * BK);
+        }
+    };
+
+    issue(0, 0);
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const bf16* cA = sA + (kt & 1) * BM * BK;
+        const bf16* cW = sW + (kt & 1) * BN * BK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], wf[NJ];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wm * 64 + i * 16 + fr;
+                const int c = (ks * 4 + fg) ^ (r & 7);
+                af[i] = *(const bf16x8*)(cA + r * BK + c * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int r = wn * (BN / 2) + j * 16 + fr;
+                const int c = (ks * 4 + fg) ^ (r & 7);
+                wf[j] = *(const bf16x8*)(cW + r * BK + c * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);   // D[n][m]: lane owns 4 consecutive n
+        }
+    }
+
+    // bias: 4 consecutive columns per lane and column tile, loaded once
+    f32x4 bv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            bv[j] = *(const f32x4*)(p.bias + bn * BN + wn * (BN / 2) + j * 16 + fg * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = bm * BM + wm * 64 + i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = bn * BN + wn * (BN / 2) + j * 16 + fg * 4;
+            epilogue_store<EPI>(p, m, n, acc[i][j] + bv[j]);
+        }
+    }
+}
+
+template <int BN, int EPI>
+void launch_t(const GemmArgs& a, hipStream_t s) {
+    const int ntiles = (a.M / BM) * (a.N / BN);
+    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16);
+    hipLaunchKernelGGL((gemm_nt_kernel<BN, EPI>), dim3(ntiles), dim3(256), lds, s, a);
+}
+
+template <int BN, int EPI>
+void set_attr() {
+    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+}  // namespace
+
+void gemm_init() {
+    static bool done = false;
+    if (done) return;
+    set_attr<64, EPI_STORE_BF16>();
+    set_attr<128, EPI_STORE_BF16>();
+    set_attr<128, EPI_RESID_F32>();
+    set_attr<128, EPI_GELU>();
+    set_attr<128, EPI_GELU_BWD>();
+    set_attr<128, EPI_PATCH_FWD>();
+    set_attr<128, EPI_PATCH_BWD>();
+    set_attr<128, EPI_STORE_F32>();
+    done = true;
+}
+
+void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
+    if (bn == 64) {
+        switch (epi) {
+            case EPI_STORE_BF16: launch_t<64, EPI_STORE_BF16>(a, s); return;
+            default: break;
+        }
+    }
+    switch (epi) {
+        case EPI_STORE_BF16: launch_t<128, EPI_STORE_BF16>(a, s); break;
+        case EPI_RESID_F32: launch_t<128, EPI_RESID_F32>(a, s); break;
+        case EPI_GELU: launch_t<128, EPI_GELU>(a, s); break;
+        case EPI_GELU_BWD: launch_t<128, EPI_GELU_BWD>(a, s); break;
+        case EPI_PATCH_FWD: launch_t<128, EPI_PATCH_FWD>(a, s); break;
+        case EPI_PATCH_BWD: launch_t<128, EPI_PATCH_BWD>(a, s); break;
+        case EPI_STORE_F32: launch_t<128, EPI_STORE_F32>(a, s); break;
+    }
+}

@@ -1,0 +1,713 @@
+// C ABI of libvitlora_hip.so (include/vitlora.h): model handle, packed weights, workspace
+// plan and the launch sequences for forward, backward-to-input, LoRA backward and the PGD
+// loop (one hipGraph per iteration).  Host-side orchestration only: all arithmetic is in
+// gemm.hip / attention.hip / elementwise.hip / lora_grad.hip.
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vitlora.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) return fail(VL_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+
+enum { LQKV = 0, LO = 1, LFC1 = 2, LFC2 = 3 };
+const uint32_t kTargetBits[6] = {VL_T_Q, VL_T_K, VL_T_V, VL_T_O, VL_T_FC1, VL_T_FC2};
+
+struct Slot {           // one adapted module inside a fused projection
+    int target_idx;     // 0..5 (q,k,v,o,fc1,fc2)
+    int row_off;        // first output row of the module inside the fused projection
+    int out, in;
+    int ext_off;        // first column of its r slots inside the K extension
+    int64_t a_off, b_off;  // offsets into the flat parameter buffer
+};
+
+struct Linear {
+    int out = 0, in = 0;
+    bf16* W = nullptr;    // [out, in]
+    bf16* WT = nullptr;   // [in, out]
+    float* bias = nullptr;
+    float* Wf32 = nullptr;   // fp32 master (kept only when adapters may be merged into W)
+    int kext = 0;
+    std::vector<Slot> slots;
+    bf16* Ad = nullptr;   // [kext, in]   t = x Ad^T
+    bf16* Bu = nullptr;   // [out, kext]  y += t Bu^T        (scaling folded in)
+    bf16* Bd = nullptr;   // [kext, out]  u = dy Bd^T
+    bf16* Au = nullptr;   // [in, kext]   dx += u Au^T       (scaling folded in)
+};
+
+struct Layer {
+    Linear lin[4];
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+};
+
+struct Workspace {
+    char* base = nullptr;
+    size_t bytes = 0;
+    int max_batch = 0, train = 0;
+    int64_t Mpad = 0, Mppad = 0;
+    bf16* patches;
+    std::vector<float*> xs;          // 2L+1 residual-stream snapshots [Mpad, D]
+    std::vector<float*> mean, rstd;  // 2L
+    std::vector<bf16*> h1, h2, a;    // per layer in train mode, shared otherwise
+    std::vector<bf16*> qkv, ctx, z;
+    std::vector<float*> lse;
+    std::vector<bf16*> t[4];         // LoRA down outputs (per layer in train mode)
+    float *xhat, *xf, *rstd_f, *logits, *dlogits, *loss;
+    float* dres[2];
+    bf16 *dres_bf, *dh, *dctx, *dqkv, *dz, *u;
+    float* grad_img;                 // [max_batch, 3, S, S] for vl_pgd_attack
+};
+
+}  // namespace
+
+struct vl_model {
+    vl_config cfg;
+    int D, L, H, MLP, S, P, G, NP, T, C, PK;   // PK = 3*P*P
+    int r = 0;
+    float scaling = 0.f;
+    // embeddings / head
+    bf16 *Wpe = nullptr, *WpeT = nullptr;
+    float *bpe = nullptr, *cls = nullptr, *pos = nullptr, *lnf_g = nullptr, *lnf_b = nullptr;
+    std::vector<Layer> layers;
+    std::vector<void*> allocs;
+    // flat trainable parameters: [layer][target]{A,B} ..., classifier W, classifier b
+    float* flat = nullptr;
+    int64_t flat_n = 0, cls_w_off = 0, cls_b_off = 0;
+    Workspace ws;
+    // state of the last forward
+    int cur_B = 0, cur_norm = 0, cur_train = 0, have_loss = 0;
+    // PGD graph cache
+    hipGraphExec_t graph_exec = nullptr;
+    struct { const void* x0; const void* labels; void* adv; int B; float eps, alpha; } gkey = {};
+    int use_graph = 1;
+    int plan_batch = 0, plan_train = 0;
+    float mean[3] = {0.485f, 0.456f, 0.406f};   // get_normalization, Utils.py:92-93
+    float stdv[3] = {0.229f, 0.224f, 0.225f};
+};
+
+namespace {
+
+template <typename Tp>
+int dev_alloc(vl_model* m, Tp** p, size_t n) {
+    void* q = nullptr;
+    if (hipMalloc(&q, n * sizeof(Tp) + 256) != hipSuccess) return fail(VL_ERR_HIP, "hipMalloc(%zu) failed", n * sizeof(Tp));
+    if (hipMemset(q, 0, n * sizeof(Tp) + 256) != hipSuccess) return fail(VL_ERR_HIP, "hipMemset failed");
+    m->allocs.push_back(q);
+    *p = (Tp*)q;
+    return VL_OK;
+}
+
+GemmArgs gemm_args(const bf16* A, int lda, const bf16* W, int ldw, int K, int M, int N) {
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.A1 = A; g.lda1 = lda; g.W1 = W; g.ldw1 = ldw; g.K1 = K;
+    g.M = M; g.Mvalid = M; g.N = N;
+    return g;
+}
+
+void add_ext(GemmArgs& g, const bf16* A2, int lda2, const bf16* W2, int ldw2, int K2) {
+    g.A2 = A2; g.lda2 = lda2; g.W2 = W2; g.ldw2 = ldw2; g.K2 = K2;
+}
+
+// y = x W^T (+ LoRA) with epilogue; `t` receives the LoRA down projection when fused.
+void linear_fwd(vl_model* m, const Linear& ln, const bf16* x, bf16* t, int Mpad, GemmArgs g, int epi, hipStream_t s) {
+    g.A1 = x; g.lda1 = ln.in; g.W1 = ln.W; g.ldw1 = ln.in; g.K1 = ln.in;
+    g.M = Mpad; g.N = ln.out; g.bias = ln.bias;
+    if (!g.Mvalid) g.Mvalid = Mpad;
+    if (ln.kext && !m->cfg.lora_merged) {
+        GemmArgs d = gemm_args(x, ln.in, ln.Ad, ln.in, ln.in, Mpad, ln.kext);
+        d.C = t; d.ldc = ln.kext;
+        launch_gemm(d, EPI_STORE_BF16, 64, s);
+        add_ext(g, t, ln.kext, ln.Bu, ln.kext, ln.kext);
+    }
+    launch_gemm(g, epi, 128, s);
+}
+
+// dx = dy W (+ LoRA) with epilogue; `u` receives dy B.
+void linear_dgrad(vl_model* m, const Linear& ln, const bf16* dy, bf16* u, int Mpad, GemmArgs g, int epi, hipStream_t s) {
+    g.A1 = dy; g.lda1 = ln.out; g.W1 = ln.WT; g.ldw1 = ln.out; g.K1 = ln.out;
+    g.M = Mpad; g.N = ln.in; g.bias = nullptr;
+    if (!g.Mvalid) g.Mvalid = Mpad;
+    if (ln.kext && !m->cfg.lora_merged) {
+        GemmArgs d = gemm_args(dy, ln.out, ln.Bd, ln.out, ln.out, Mpad, ln.kext);
+        d.C = u; d.ldc = ln.kext;
+        launch_gemm(d, EPI_STORE_BF16, 64, s);
+        add_ext(g, u, ln.kext, ln.Au, ln.kext, ln.kext);
+    }
+    launch_gemm(g, epi, 128, s);
+}
+
+int parse_layer(const char* name, const char** rest) {
+    // "vit.encoder.layer.<i>.<rest>"
+    const char* pfx = "vit.encoder.layer.";
+    const size_t n = strlen(pfx);
+    if (strncmp(name, pfx, n) != 0) return -1;
+    char* end = nullptr;
+    long i = strtol(name + n, &end, 10);
+    if (end == name + n || *end != '.') return -1;
+    *rest = end + 1;
+    return (int)i;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vl_version(void) { return "vitlora-hip 0.1 (gfx950)"; }
+const char* vl_last_error(void) { return g_err.c_str(); }
+
+int vl_create(const vl_config* cfg, vl_model** out) {
+    if (!cfg || !out) return fail(VL_ERR_ARG, "null argument");
+    if (cfg->heads <= 0 || cfg->hidden != cfg->heads * 64)
+        return fail(VL_ERR_UNSUPPORTED, "head_dim must be 64 (hidden %d, heads %d)", cfg->hidden, cfg->heads);
+    if (cfg->hidden % 128 || cfg->mlp % 128) return fail(VL_ERR_UNSUPPORTED, "hidden and mlp must be multiples of 128");
+    if (cfg->image_size % cfg->patch_size || cfg->patch_size % 8)
+        return fail(VL_ERR_UNSUPPORTED, "image_size %% patch_size != 0 or patch_size %% 8 != 0");
+    if ((3 * cfg->patch_size * cfg->patch_size) % 128) return fail(VL_ERR_UNSUPPORTED, "3*patch^2 must be a multiple of 128");
+    const int G = cfg->image_size / cfg->patch_size;
+    if (G * G + 1 > 224) return fail(VL_ERR_UNSUPPORTED, "at most 224 tokens");
+    if (cfg->lora_r < 0 || cfg->lora_r > 64) return fail(VL_ERR_UNSUPPORTED, "lora_r must be in [0,64]");
+    if (cfg->num_labels <= 0) return fail(VL_ERR_ARG, "num_labels must be positive");
+
+    gemm_init();
+    attention_init();
+    vl_model* m = new vl_model();
+    m->cfg = *cfg;
+    m->D = cfg->hidden; m->L = cfg->layers; m->H = cfg->heads; m->MLP = cfg->mlp;
+    m->S = cfg->image_size; m->P = cfg->patch_size; m->G = G; m->NP = G * G; m->T = G * G + 1;
+    m->C = cfg->num_labels; m->PK = 3 * cfg->patch_size * cfg->patch_size;
+    m->r = cfg->lora_targets ? cfg->lora_r : 0;
+    m->scaling = m->r ? cfg->lora_alpha / (float)m->r : 0.f;
+    const char* ng = getenv("VITLORA_NO_GRAPH");
+    m->use_graph = !(ng && ng[0] == '1');
+    const int D = m->D, MLP = m->MLP, r = m->r;
+    int rc;
+#define A_(p, n) if ((rc = dev_alloc(m, &(p), (size_t)(n))) != VL_OK) { vl_destroy(m); return rc; }
+    A_(m->Wpe, (size_t)D * m->PK); A_(m->WpeT, (size_t)m->PK * D); A_(m->bpe, D); A_(m->cls, D);
+    A_(m->pos, (size_t)m->T * D); A_(m->lnf_g, D); A_(m->lnf_b, D);
+    // flat parameter layout
+    int64_t off = 0;
+    m->layers.resize(m->L);
+    for (int l = 0; l < m->L; ++l) {
+        Layer& ly = m->layers[l];
+        const int outs[4] = {3 * D, D, MLP, D}, ins[4] = {D, D, D, MLP};
+        for (int k = 0; k < 4; ++k) {
+            Linear& ln = ly.lin[k];
+            ln.out = outs[k]; ln.in = ins[k];
+            A_(ln.W, (size_t)ln.out * ln.in); A_(ln.WT, (size_t)ln.out * ln.in); A_(ln.bias, ln.out);
+        }
+        A_(ly.ln1_g, D); A_(ly.ln1_b, D); A_(ly.ln2_g, D); A_(ly.ln2_b, D);
+        if (r) {
+            // slots: q,k,v inside the fused qkv projection; o, fc1, fc2 alone
+            const int lin_of[6] = {LQKV, LQKV, LQKV, LO, LFC1, LFC2};
+            const int row_of[6] = {0, D, 2 * D, 0, 0, 0};
+            const int out_of[6] = {D, D, D, D, MLP, D}, in_of[6] = {D, D, D, D, D, MLP};
+            const int ext_of[6] = {0, r, 2 * r, 0, 0, 0};
+            for (int ti = 0; ti < 6; ++ti) {
+                if (!(cfg->lora_targets & kTargetBits[ti])) continue;
+                Slot sl;
+                sl.target_idx = ti; sl.row_off = row_of[ti]; sl.out = out_of[ti]; sl.in = in_of[ti];
+                sl.ext_off = ext_of[ti];
+                sl.a_off = off; off += (int64_t)r * sl.in;
+                sl.b_off = off; off += (int64_t)sl.out * r;
+                ly.lin[lin_of[ti]].slots.push_back(sl);
+            }
+            for (int k = 0; k < 4; ++k) {
+                Linear& ln = ly.lin[k];
+                if (ln.slots.empty()) continue;
+                ln.kext = (int)round_up(k == LQKV ? 3 * r : r, 64);
+                if (cfg->lora_merged) { A_(ln.Wf32, (size_t)ln.out * ln.in); }
+                else {
+                    A_(ln.Ad, (size_t)ln.kext * ln.in); A_(ln.Bu, (size_t)ln.out * ln.kext);
+                    A_(ln.Bd, (size_t)ln.kext * ln.out); A_(ln.Au, (size_t)ln.in * ln.kext);
+                }
+            }
+        }
+    }
+    m->cls_w_off = off; off += (int64_t)m->C * D;
+    m->cls_b_off = off; off += m->C;
+    m->flat_n = off;
+    A_(m->flat, (size_t)off);
+#undef A_
+    *out = m;
+    return VL_OK;
+}
+
+int vl_destroy(vl_model* m) {
+    if (!m) return VL_OK;
+    if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+    for (void* p : m->allocs) (void)hipFree(p);
+    delete m;
+    return VL_OK;
+}
+
+int vl_load_tensor(vl_model* m, const char* name, const float* src, int64_t numel, void* stream) {
+    if (!m || !name || !src) return fail(VL_ERR_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int D = m->D;
+    auto copyf = [&](float* dst, int64_t n) -> int {
+        if (n != numel) return fail(VL_ERR_ARG, "%s: expected %lld elements, got %lld", name, (long long)n, (long long)numel);
+        HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return VL_OK;
+    };
+    auto need = [&](int64_t n) -> int {
+        return n == numel ? VL_OK : fail(VL_ERR_ARG, "%s: expected %lld elements, got %lld", name, (long long)n, (long long)numel);
+    };
+    int rc;
+    if (!strcmp(name, "vit.embeddings.cls_token")) return copyf(m->cls, D);
+    if (!strcmp(name, "vit.embeddings.position_embeddings")) return copyf(m->pos, (int64_t)m->T * D);
+    if (!strcmp(name, "vit.embeddings.patch_embeddings.projection.weight")) {
+        if ((rc = need((int64_t)D * m->PK))) return rc;
+        k_pack_bf16(src, m->Wpe, D, m->PK, m->PK, 0, 1.f, s);
+        k_pack_bf16_t(src, m->WpeT, D, m->PK, D, 0, 1.f, s);
+        return VL_OK;
+    }
+    if (!strcmp(name, "vit.embeddings.patch_embeddings.projection.bias")) return copyf(m->bpe, D);
+    if (!strcmp(name, "vit.layernorm.weight")) return copyf(m->lnf_g, D);
+    if (!strcmp(name, "vit.layernorm.bias")) return copyf(m->lnf_b, D);
+    if (!strcmp(name, "classifier.weight")) return copyf(m->flat + m->cls_w_off, (int64_t)m->C * D);
+    if (!strcmp(name, "classifier.bias")) return copyf(m->flat + m->cls_b_off, m->C);
+    const char* rest = nullptr;
+    const int li = parse_layer(name, &rest);
+    if (li < 0 || li >= m->L) return fail(VL_ERR_ARG, "unknown tensor name: %s", name);
+    Layer& ly = m->layers[li];
+    if (!strcmp(rest, "layernorm_before.weight")) return copyf(ly.ln1_g, D);
+    if (!strcmp(rest, "layernorm_before.bias")) return copyf(ly.ln1_b, D);
+    if (!strcmp(rest, "layernorm_after.weight")) return copyf(ly.ln2_g, D);
+    if (!strcmp(rest, "layernorm_after.bias")) return copyf(ly.ln2_b, D);
+    struct { const char* mod; int lin; int row_off; } mods[6] = {
+        {"attention.attention.query.", LQKV, 0}, {"attention.attention.key.", LQKV, D},
+        {"attention.attention.value.", LQKV, 2 * D}, {"attention.output.dense.", LO, 0},
+        {"intermediate.dense.", LFC1, 0}, {"output.dense.", LFC2, 0}};
+    for (auto& md : mods) {
+        const size_t n = strlen(md.mod);
+        if (strncmp(rest, md.mod, n) != 0) continue;
+        Linear& ln = ly.lin[md.lin];
+        const int rows = md.lin == LQKV ? D : ln.out;
+        if (!strcmp(rest + n, "weight")) {
+            if ((rc = need((int64_t)rows * ln.in))) return rc;
+            k_pack_bf16(src, ln.W + (size_t)md.row_off * ln.in, rows, ln.in, ln.in, 0, 1.f, s);
+            k_pack_bf16_t(src, ln.WT, rows, ln.in, ln.out, md.row_off, 1.f, s);
+            if (ln.Wf32)
+                HIPCHK(hipMemcpyAsync(ln.Wf32 + (size_t)md.row_off * ln.in, src, (size_t)rows * ln.in * sizeof(float),
+                                      hipMemcpyDeviceToDevice, s));
+            return VL_OK;
+        }
+        if (!strcmp(rest + n, "bias")) {
+            if ((rc = need(rows))) return rc;
+            HIPCHK(hipMemcpyAsync(ln.bias + md.row_off, src, rows * sizeof(float), hipMemcpyDeviceToDevice, s));
+            return VL_OK;
+        }
+    }
+    return fail(VL_ERR_ARG, "unknown tensor name: %s", name);
+}
+
+int vl_param_flat(vl_model* m, float** ptr, int64_t* numel) {
+    if (!m) return fail(VL_ERR_ARG, "null model");
+    if (ptr) *ptr = m->flat;
+    if (numel) *numel = m->flat_n;
+    return VL_OK;
+}
+
+int vl_param_tensor(vl_model* m, int layer, uint32_t target, int which, float** ptr, int64_t* numel) {
+    if (!m || !ptr || !numel) return fail(VL_ERR_ARG, "null argument");
+    if (layer < 0) {
+        *ptr = m->flat + (which == 0 ? m->cls_w_off : m->cls_b_off);
+        *numel = which == 0 ? (int64_t)m->C * m->D : m->C;
+        return VL_OK;
+    }
+    if (layer >= m->L) return fail(VL_ERR_ARG, "layer %d out of range", layer);
+    for (int k = 0; k < 4; ++k)
+        for (const Slot& sl : m->layers[layer].lin[k].slots)
+            if (kTargetBits[sl.target_idx] == target) {
+                *ptr = m->flat + (which == 0 ? sl.a_off : sl.b_off);
+                *numel = which == 0 ? (int64_t)m->r * sl.in : (int64_t)sl.out * m->r;
+                return VL_OK;
+            }
+    return fail(VL_ERR_ARG, "target 0x%x has no adapter in layer %d", target, layer);
+}
+
+int vl_lora_commit(vl_model* m, void* stream) {
+    if (!m) return fail(VL_ERR_ARG, "null model");
+    hipStream_t s = (hipStream_t)stream;
+    const int r = m->r;
+    if (!r) return VL_OK;
+    for (Layer& ly : m->layers)
+        for (int k = 0; k < 4; ++k) {
+            Linear& ln = ly.lin[k];
+            for (const Slot& sl : ln.slots) {
+                const float* A = m->flat + sl.a_off;   // [r, in]
+                const float* B = m->flat + sl.b_off;   // [out, r]
+                if (m->cfg.lora_merged) {
+                    k_merge_lora(ln.Wf32 + (size_t)sl.row_off * ln.in, A, B, sl.out, sl.in, r, m->scaling, ln.W, ln.in,
+                                 sl.row_off, ln.WT, ln.out, sl.row_off, s);
+                } else {
+                    k_pack_bf16(A, ln.Ad + (size_t)sl.ext_off * ln.in, r, sl.in, ln.in, 0, 1.f, s);
+                    k_pack_bf16(B, ln.Bu + (size_t)sl.row_off * ln.kext, sl.out, r, ln.kext, sl.ext_off, m->scaling, s);
+                    k_pack_bf16_t(B, ln.Bd + (size_t)sl.ext_off * ln.out, sl.out, r, ln.out, sl.row_off, 1.f, s);
+                    k_pack_bf16_t(A, ln.Au, r, sl.in, ln.kext, sl.ext_off, m->scaling, s);
+                }
+            }
+        }
+    return VL_OK;
+}
+
+// ---- workspace -------------------------------------------------------------------------------
+static size_t carve(vl_model* m, int B, int train, char* base) {
+    Workspace& w = m->ws;
+    const int D = m->D, L = m->L, MLP = m->MLP;
+    const int64_t Mpad = round_up((int64_t)B * m->T, 128), Mppad = round_up((int64_t)B * m->NP, 128);
+    size_t off = 0;
+    auto take = [&](size_t bytes) -> char* {
+        char* p = base ? base + off : nullptr;
+        off += (size_t)round_up((int64_t)bytes, 256);
+        return p;
+    };
+    w.Mpad = Mpad; w.Mppad = Mppad;
+    w.patches = (bf16*)take((size_t)Mppad * m->PK * 2);
+    w.xs.resize(2 * L + 1);
+    for (auto& p : w.xs) p = (float*)take((size_t)Mpad * D * 4);
+    w.mean.resize(2 * L); w.rstd.resize(2 * L);
+    for (int i = 0; i < 2 * L; ++i) { w.mean[i] = (float*)take(Mpad * 4); w.rstd[i] = (float*)take(Mpad * 4); }
+    w.h1.resize(L); w.h2.resize(L); w.a.resize(L); w.qkv.resize(L); w.ctx.resize(L); w.z.resize(L); w.lse.resize(L);
+    int kext_max = 64;
+    for (int k = 0; k < 4; ++k) { w.t[k].resize(L); if (m->layers[0].lin[k].kext > kext_max) kext_max = m->layers[0].lin[k].kext; }
+    bf16* sh_h = train ? nullptr : (bf16*)take((size_t)Mpad * D * 2);
+    bf16* sh_a = train ? nullptr : (bf16*)take((size_t)Mpad * MLP * 2);
+    bf16* sh_t = train ? nullptr : (bf16*)take((size_t)Mpad * kext_max * 2);
+    for (int l = 0; l < L; ++l) {
+        w.h1[l] = train ? (bf16*)take((size_t)Mpad * D * 2) : sh_h;
+        w.h2[l] = train ? (bf16*)take((size_t)Mpad * D * 2) : sh_h;
+        w.a[l] = train ? (bf16*)take((size_t)Mpad * MLP * 2) : sh_a;
+        w.qkv[l] = (bf16*)take((size_t)Mpad * 3 * D * 2);
+        w.ctx[l] = (bf16*)take((size_t)Mpad * D * 2);
+        w.z[l] = (bf16*)take((size_t)Mpad * MLP * 2);
+        w.lse[l] = (float*)take((size_t)B * m->H * m->T * 4);
+        for (int k = 0; k < 4; ++k)
+            w.t[k][l] = train ? (bf16*)take((size_t)Mpad * kext_max * 2) : sh_t;
+    }
+    w.xhat = (float*)take((size_t)B * D * 4); w.xf = (float*)take((size_t)B * D * 4);
+    w.rstd_f = (float*)take((size_t)B * 4);
+    w.logits = (float*)take((size_t)B * m->C * 4); w.dlogits = (float*)take((size_t)B * m->C * 4);
+    w.loss = (float*)take(256);
+    w.dres[0] = (float*)take((size_t)Mpad * D * 4); w.dres[1] = (float*)take((size_t)Mpad * D * 4);
+    w.dres_bf = (bf16*)take((size_t)Mpad * D * 2);
+    w.dh = (bf16*)take((size_t)Mpad * D * 2);
+    w.dctx = (bf16*)take((size_t)Mpad * D * 2);
+    w.dqkv = (bf16*)take((size_t)Mpad * 3 * D * 2);
+    w.dz = (bf16*)take((size_t)Mpad * MLP * 2);
+    w.u = (bf16*)take((size_t)Mpad * kext_max * 2);
+    w.grad_img = (float*)take((size_t)B * 3 * m->S * m->S * 4);
+    return off;
+}
+
+int vl_plan(vl_model* m, int max_batch, int train, size_t* bytes) {
+    if (!m || !bytes || max_batch <= 0) return fail(VL_ERR_ARG, "bad argument");
+    *bytes = carve(m, max_batch, train, nullptr);
+    m->ws.max_batch = 0;   // a plan alone does not arm the workspace
+    m->plan_batch = max_batch; m->plan_train = train;
+    return VL_OK;
+}
+
+// arms the workspace for the (max_batch, train) of the last vl_plan
+int vl_set_workspace(vl_model* m, void* wsp, size_t bytes) {
+    if (!m || !wsp) return fail(VL_ERR_ARG, "null argument");
+    if (m->plan_batch <= 0) return fail(VL_ERR_STATE, "vl_set_workspace before vl_plan");
+    const int max_batch = m->plan_batch, train = m->plan_train;
+    if (((uintptr_t)wsp) & 255) return fail(VL_ERR_ARG, "workspace must be 256-byte aligned");
+    const size_t need = carve(m, max_batch, train, nullptr);
+    if (bytes < need) return fail(VL_ERR_ARG, "workspace too small: %zu < %zu", bytes, need);
+    carve(m, max_batch, train, (char*)wsp);
+    m->ws.base = (char*)wsp; m->ws.bytes = bytes; m->ws.max_batch = max_batch; m->ws.train = train;
+    if (hipMemset(wsp, 0, need) != hipSuccess) return fail(VL_ERR_HIP, "hipMemset(workspace) failed");
+    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    m->cur_B = 0;
+    return VL_OK;
+}
+
+// ---- forward ---------------------------------------------------------------------------------
+static int forward_impl(vl_model* m, const float* x, int B, int normalise, int train, hipStream_t s) {
+    Workspace& w = m->ws;
+    if (B <= 0 || B > w.max_batch) return fail(VL_ERR_STATE, "batch %d exceeds planned workspace (%d)", B, w.max_batch);
+    if (train && !w.train) return fail(VL_ERR_STATE, "workspace was not planned for training");
+    if (train && m->cfg.lora_merged) return fail(VL_ERR_STATE, "training needs lora_merged = 0");
+    if (train && m->r && m->cfg.lora_dropout > 0.f)
+        return fail(VL_ERR_UNSUPPORTED, "lora_dropout > 0 in train mode is not implemented yet");
+    const int D = m->D, L = m->L, T = m->T;
+    const int Mpad = (int)round_up((int64_t)B * T, 128), Mppad = (int)round_up((int64_t)B * m->NP, 128);
+    const int M = B * T;
+    k_patch_gather(x, w.patches, B, m->S, m->P, normalise, m->mean, m->stdv, s);
+    {
+        GemmArgs g = gemm_args(w.patches, m->PK, m->Wpe, m->PK, m->PK, Mppad, D);
+        g.Mvalid = B * m->NP; g.bias = m->bpe; g.C = w.xs[0]; g.ldc = D;
+        g.pos = m->pos; g.tokens = T; g.patches = m->NP;
+        launch_gemm(g, EPI_PATCH_FWD, 128, s);
+    }
+    k_cls_rows(w.xs[0], m->cls, m->pos, B, T, D, s);
+    for (int l = 0; l < L; ++l) {
+        Layer& ly = m->layers[l];
+        GemmArgs g;
+        k_layernorm_fwd(w.xs[2 * l], w.h1[l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, ly.ln1_b, M, D, m->cfg.ln_eps, s);
+        memset(&g, 0, sizeof g); g.C = w.qkv[l]; g.ldc = 3 * D;
+        linear_fwd(m, ly.lin[LQKV], w.h1[l], w.t[LQKV][l], Mpad, g, EPI_STORE_BF16, s);
+        if (k_attention_fwd(w.qkv[l], w.ctx[l], w.lse[l], B, T, m->H, D, s)) return fail(VL_ERR_UNSUPPORTED, "attention: T > 224");
+        memset(&g, 0, sizeof g); g.C = w.xs[2 * l + 1]; g.ldc = D; g.R = w.xs[2 * l]; g.ldr = D;
+        linear_fwd(m, ly.lin[LO], w.ctx[l], w.t[LO][l], Mpad, g, EPI_RESID_F32, s);
+        k_layernorm_fwd(w.xs[2 * l + 1], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D,
+                        m->cfg.ln_eps, s);
+        memset(&g, 0, sizeof g); g.C = w.a[l]; g.ldc = m->MLP; g.C2 = w.z[l]; g.ldc2 = m->MLP;
+        linear_fwd(m, ly.lin[LFC1], w.h2[l], w.t[LFC1][l], Mpad, g, EPI_GELU, s);
+        memset(&g, 0, sizeof g); g.C = w.xs[2 * l + 2]; g.ldc = D; g.R = w.xs[2 * l + 1]; g.ldr = D;
+        linear_fwd(m, ly.lin[LFC2], w.a[l], w.t[LFC2][l], Mpad, g, EPI_RESID_F32, s);
+    }
+    k_head_fwd(w.xs[2 * L], B, T, D, m->C, m->cfg.ln_eps, m->lnf_g, m->lnf_b, m->flat + m->cls_w_off,
+               m->flat + m->cls_b_off, w.xhat, w.xf, w.rstd_f, w.logits, s);
+    m->cur_B = B; m->cur_norm = normalise; m->cur_train = train; m->have_loss = 0;
+    return VL_OK;
+}
+
+int vl_forward(vl_model* m, const float* x, int batch, int normalise, int train, float* logits_out, void* stream) {
+    if (!m || !x) return fail(VL_ERR_ARG, "null argument");
+    if (!m->ws.max_batch) return fail(VL_ERR_STATE, "no workspace: call vl_plan + vl_set_workspace first");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = forward_impl(m, x, batch, normalise, train, s);
+    if (rc) return rc;
+    if (logits_out)
+        HIPCHK(hipMemcpyAsync(logits_out, m->ws.logits, (size_t)batch * m->C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return VL_OK;
+}
+
+int vl_loss_ce(vl_model* m, const int64_t* labels, float* loss_out, void* stream) {
+    if (!m || !labels) return fail(VL_ERR_ARG, "null argument");
+    if (!m->cur_B) return fail(VL_ERR_STATE, "vl_loss_ce before vl_forward");
+    hipStream_t s = (hipStream_t)stream;
+    k_ce_loss(m->ws.logits, labels, m->cur_B, m->C, m->ws.dlogits, m->ws.loss, s);
+    if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, m->ws.loss, sizeof(float), hipMemcpyDeviceToDevice, s));
+    m->have_loss = 1;
+    return VL_OK;
+}
+
+// ---- backward --------------------------------------------------------------------------------
+// shared dgrad chain; flat_grad != null additionally produces the LoRA / classifier gradients,
+// grad_x != null the input gradient.
+static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream_t s) {
+    Workspace& w = m->ws;
+    if (!m->have_loss) return fail(VL_ERR_STATE, "backward before vl_loss_ce");
+    const int B = m->cur_B, D = m->D, L = m->L, T = m->T, MLP = m->MLP, r = m->r;
+    const int Mpad = (int)round_up((int64_t)B * T, 128), Mppad = (int)round_up((int64_t)B * m->NP, 128);
+    const int M = B * T;
+    const float sc = m->scaling;
+    if (flat_grad) {
+        if (!m->cur_train) return fail(VL_ERR_STATE, "vl_backward_lora needs vl_forward(train=1)");
+        HIPCHK(hipMemsetAsync(flat_grad, 0, (size_t)m->flat_n * sizeof(float), s));
+        k_classifier_grad(w.dlogits, w.xf, B, D, m->C, flat_grad + m->cls_w_off, flat_grad + m->cls_b_off, s);
+    }
+    int cur = 0;
+    HIPCHK(hipMemsetAsync(w.dres[0], 0, (size_t)Mpad * D * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(w.dres_bf, 0, (size_t)Mpad * D * sizeof(bf16), s));
+    k_head_bwd(w.dlogits, m->flat + m->cls_w_off, m->lnf_g, w.xhat, w.rstd_f, B, T, D, m->C, w.dres[0], w.dres_bf, s);
+
+    // LoRA weight gradients of one projection: dy [M,out], x [M,in], t/u [M,kext]
+    auto wgrad = [&](const Linear& ln, const bf16* dy, const bf16* x, const bf16* t, const bf16* u) {
+        if (!flat_grad || ln.slots.empty()) return;
+        for (const Slot& sl : ln.slots) {
+            // dB[n][j] = s * sum_m dy[m][row_off+n] * t[m][ext_off+j]
+            k_lora_wgrad(dy + sl.row_off, ln.out, sl.out, t + sl.ext_off, ln.kext, r, M, sc, flat_grad + sl.b_off, r, 0,
+                         nullptr, s);
+            // dA[j][k] = s * sum_m u[m][ext_off+j] * x[m][k]   (computed transposed: L = x)
+            k_lora_wgrad(x, ln.in, sl.in, u + sl.ext_off, ln.kext, r, M, sc, flat_grad + sl.a_off, sl.in, 1, nullptr, s);
+        }
+    };
+
+    for (int l = L - 1; l >= 0; --l) {
+        Layer& ly = m->layers[l];
+        GemmArgs g;
+        // MLP: dz = (dx2 Wfc2 (+LoRA)) * gelu'(z)
+        memset(&g, 0, sizeof g); g.C = w.dz; g.ldc = MLP; g.R = w.z[l]; g.ldr = MLP;
+        linear_dgrad(m, ly.lin[LFC2], w.dres_bf, w.u, Mpad, g, EPI_GELU_BWD, s);
+        wgrad(ly.lin[LFC2], w.dres_bf, w.a[l], w.t[LFC2][l], w.u);
+        memset(&g, 0, sizeof g); g.C = w.dh; g.ldc = D;
+        linear_dgrad(m, ly.lin[LFC1], w.dz, w.u, Mpad, g, EPI_STORE_BF16, s);
+        wgrad(ly.lin[LFC1], w.dz, w.h2[l], w.t[LFC1][l], w.u);
+        k_layernorm_bwd(w.dh, w.xs[2 * l + 1], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, w.dres[cur], w.dres[cur ^ 1],
+                        w.dres_bf, M, D, s);
+        cur ^= 1;
+        // attention block
+        memset(&g, 0, sizeof g); g.C = w.dctx; g.ldc = D;
+        linear_dgrad(m, ly.lin[LO], w.dres_bf, w.u, Mpad, g, EPI_STORE_BF16, s);
+        wgrad(ly.lin[LO], w.dres_bf, w.ctx[l], w.t[LO][l], w.u);
+        if (k_attention_bwd(w.qkv[l], w.ctx[l], w.dctx, w.lse[l], w.dqkv, B, T, m->H, D, s))
+            return fail(VL_ERR_UNSUPPORTED, "attention: T > 224");
+        memset(&g, 0, sizeof g); g.C = w.dh; g.ldc = D;
+        linear_dgrad(m, ly.lin[LQKV], w.dqkv, w.u, Mpad, g, EPI_STORE_BF16, s);
+        wgrad(ly.lin[LQKV], w.dqkv, w.h1[l], w.t[LQKV][l], w.u);
+        k_layernorm_bwd(w.dh, w.xs[2 * l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, w.dres[cur], w.dres[cur ^ 1], w.dres_bf,
+                        M, D, s);
+        cur ^= 1;
+    }
+    if (grad_x) {
+        // d(pixels): patch rows of d(x0) times Wpe, scattered back to NCHW, chain rule of (x-mean)/std
+        GemmArgs g = gemm_args(w.dres_bf, D, m->WpeT, D, D, Mppad, m->PK);
+        g.Mvalid = B * m->NP; g.C = grad_x; g.a_gather = 1;
+        g.tokens = T; g.patches = m->NP; g.grid = m->G; g.psize = m->P; g.img = m->S;
+        for (int c = 0; c < 3; ++c) g.inv_std[c] = m->cur_norm ? 1.f / m->stdv[c] : 1.f;
+        launch_gemm(g, EPI_PATCH_BWD, 128, s);
+    }
+    return VL_OK;
+}
+
+int vl_set_dlogits(vl_model* m, const float* dlogits, void* stream) {
+    if (!m || !dlogits) return fail(VL_ERR_ARG, "null argument");
+    if (!m->cur_B) return fail(VL_ERR_STATE, "vl_set_dlogits before vl_forward");
+    HIPCHK(hipMemcpyAsync(m->ws.dlogits, dlogits, (size_t)m->cur_B * m->C * sizeof(float), hipMemcpyDeviceToDevice,
+                          (hipStream_t)stream));
+    m->have_loss = 1;
+    return VL_OK;
+}
+
+int vl_backward(vl_model* m, float* grad_x_out, float* flat_grad_out, void* stream) {
+    if (!m || (!grad_x_out && !flat_grad_out)) return fail(VL_ERR_ARG, "null argument");
+    return backward_impl(m, grad_x_out, flat_grad_out, (hipStream_t)stream);
+}
+
+int vl_set_normalization(vl_model* m, const float mean[3], const float stdv[3]) {
+    if (!m || !mean || !stdv) return fail(VL_ERR_ARG, "null argument");
+    for (int c = 0; c < 3; ++c) {
+        if (!(stdv[c] > 0.f)) return fail(VL_ERR_ARG, "std must be positive");
+        m->mean[c] = mean[c]; m->stdv[c] = stdv[c];
+    }
+    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    return VL_OK;
+}
+
+int vl_channel_affine(float* dst, const float* src, const float scale[3], const float shift[3], int batch, int64_t hw,
+                      void* stream) {
+    if (!dst || !src || !scale || !shift || batch <= 0 || hw <= 0) return fail(VL_ERR_ARG, "bad argument");
+    k_channel_affine(dst, src, scale, shift, batch, hw, (hipStream_t)stream);
+    return VL_OK;
+}
+
+int vl_backward_input(vl_model* m, float* grad_x_out, void* stream) {
+    if (!m || !grad_x_out) return fail(VL_ERR_ARG, "null argument");
+    return backward_impl(m, grad_x_out, nullptr, (hipStream_t)stream);
+}
+
+int vl_backward_lora(vl_model* m, float* flat_grad_out, void* stream) {
+    if (!m || !flat_grad_out) return fail(VL_ERR_ARG, "null argument");
+    return backward_impl(m, nullptr, flat_grad_out, (hipStream_t)stream);
+}
+
+// ---- attacks ---------------------------------------------------------------------------------
+int vl_pgd_step(float* adv, const float* x0, const float* grad, float eps, float alpha, float lo, float hi, int64_t n,
+                void* stream) {
+    if (!adv || !x0 || !grad || n <= 0) return fail(VL_ERR_ARG, "bad argument");
+    k_pgd_step(adv, x0, grad, eps, alpha, lo, hi, n, (hipStream_t)stream);
+    return VL_OK;
+}
+
+int vl_pgd_init(float* adv, const float* x0, float eps, float lo, float hi, uint64_t seed, int64_t n, void* stream) {
+    if (!adv || !x0 || n <= 0) return fail(VL_ERR_ARG, "bad argument");
+    k_pgd_init(adv, x0, eps, lo, hi, seed, n, (hipStream_t)stream);
+    return VL_OK;
+}
+
+static int pgd_iteration(vl_model* m, const float* x0, const int64_t* labels, int B, float eps, float alpha, float* adv,
+                         hipStream_t s) {
+    int rc = forward_impl(m, adv, B, 1, 0, s);
+    if (rc) return rc;
+    k_ce_loss(m->ws.logits, labels, B, m->C, m->ws.dlogits, m->ws.loss, s);
+    m->have_loss = 1;
+    rc = backward_impl(m, m->ws.grad_img, nullptr, s);
+    if (rc) return rc;
+    k_pgd_step(adv, x0, m->ws.grad_img, eps, alpha, 0.f, 1.f, (int64_t)B * 3 * m->S * m->S, s);
+    return VL_OK;
+}
+
+int vl_pgd_attack(vl_model* m, const float* x0, const int64_t* labels, int batch, float eps, float alpha, int steps,
+                  int random_start, uint64_t seed, float* adv_out, void* stream) {
+    if (!m || !x0 || !labels || !adv_out || adv_out == x0) return fail(VL_ERR_ARG, "bad argument");
+    if (!m->ws.max_batch) return fail(VL_ERR_STATE, "no workspace");
+    if (batch <= 0 || batch > m->ws.max_batch) return fail(VL_ERR_STATE, "batch exceeds planned workspace");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)batch * 3 * m->S * m->S;
+    if (random_start) k_pgd_init(adv_out, x0, eps, 0.f, 1.f, seed, n, s);
+    else HIPCHK(hipMemcpyAsync(adv_out, x0, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (steps <= 0) return VL_OK;
+    if (!m->use_graph) {
+        for (int i = 0; i < steps; ++i) {
+            int rc = pgd_iteration(m, x0, labels, batch, eps, alpha, adv_out, s);
+            if (rc) return rc;
+        }
+        return VL_OK;
+    }
+    const bool hit = m->graph_exec && m->gkey.x0 == x0 && m->gkey.labels == labels && m->gkey.adv == adv_out &&
+                     m->gkey.B == batch && m->gkey.eps == eps && m->gkey.alpha == alpha;
+    if (!hit) {
+        if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+        hipGraph_t graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int rc = pgd_iteration(m, x0, labels, batch, eps, alpha, adv_out, s);
+        hipError_t e = hipStreamEndCapture(s, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) return fail(VL_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(&m->graph_exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { m->graph_exec = nullptr; return fail(VL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+        m->gkey = {x0, labels, adv_out, batch, eps, alpha};
+    }
+    for (int i = 0; i < steps; ++i) HIPCHK(hipGraphLaunch(m->graph_exec, s));
+    return VL_OK;
+}
+
+int vl_adam_step(float* param, const float* grad, float* m1, float* m2, float lr, float b1, float b2, float eps, int t,
+                 int64_t n, void* stream) {
+    if (!param || !grad || !m1 || !m2 || n <= 0 || t <= 0) return fail(VL_ERR_ARG, "bad argument");
+    k_adam(param, grad, m1, m2, lr, b1, b2, eps, t, n, (hipStream_t)stream);
+    return VL_OK;
+}
+
+int vl_quantize_u8(const float* images, uint8_t* out_hwc, int batch, int channels, int height, int width, void* stream) {
+    if (!images || !out_hwc) return fail(VL_ERR_ARG, "null argument");
+    k_quantize(images, out_hwc, batch, channels, height, width, (hipStream_t)stream);
+    return VL_OK;
+}
+
+int vl_debug_tensor(vl_model* m, const char* what, int layer, void** ptr, int64_t* numel, int* dtype) {
+    // dtype: 0 = f32, 1 = bf16
+    if (!m || !what || !ptr || !numel || !dtype) return fail(VL_ERR_ARG, "null argument");
+    Workspace& w = m->ws;
+    if (!w.max_batch) return fail(VL_ERR_STATE, "no workspace");
+    const int64_t MD = (int64_t)m->cur_B * m->T * m->D;
+    if (!strcmp(what, "xs")) { if (layer < 0 || layer > 2 * m->L) return fail(VL_ERR_ARG, "index"); *ptr = w.xs[layer]; *numel = MD; *dtype = 0; return VL_OK; }
+    if (layer < 0 || layer >= m->L) return fail(VL_ERR_ARG, "layer out of range");
+    if (!strcmp(what, "qkv")) { *ptr = w.qkv[layer]; *numel = 3 * MD; *dtype = 1; return VL_OK; }
+    if (!strcmp(what, "ctx")) { *ptr = w.ctx[layer]; *numel = MD; *dtype = 1; return VL_OK; }
+    if (!strcmp(what, "z")) { *ptr = w.z[layer]; *numel = (int64_t)m->cur_B * m->T * m->MLP; *dtype = 1; return VL_OK; }
+    if (!strcmp(what, "lse")) { *ptr = w.lse[layer]; *numel = (int64_t)m->cur_B * m->H * m->T; *dtype = 0; return VL_OK; }
+    return fail(VL_ERR_ARG, "unknown debug tensor %s", what);
+}
+
+}  // extern "C"

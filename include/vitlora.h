@@ -1,0 +1,165 @@
+/*
+ * vitlora.h -- C ABI of libvitlora_hip.so: the MI355X (gfx950) implementation of the
+ * ViT + LoRA + FGSM/PGD hot path of
+ *   rneddojr/Adapting-Pretrained-Vision-Transformers-with-LoRA-against-Attack-Vectors.
+ *
+ * The reference has no FFI: the path is reached through Python callables.  Each
+ * entry point below names the reference callable (file:line in /root/reference) it
+ * stands in for; INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless marked "host";
+ *   - every launch function takes a hipStream_t (as void*) and only enqueues work:
+ *     no allocation, no host synchronisation after vl_plan()/vl_set_workspace();
+ *   - return value 0 = OK, negative = error; vl_last_error() gives the message;
+ *   - one handle per device, driven by one host thread (the reference's model:
+ *     a single Python thread drives one device, whitebox_attacks.py:67).
+ */
+#ifndef VITLORA_H
+#define VITLORA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VL_OK 0
+#define VL_ERR_ARG (-1)
+#define VL_ERR_HIP (-2)
+#define VL_ERR_STATE (-3)
+#define VL_ERR_UNSUPPORTED (-4)
+
+/* LoRA target bits.  peft matches module-name suffixes: the reference's
+ * ["query","key","value","output.dense"] (train_loras.py:81) = Q|K|V|O|FC2. */
+#define VL_T_Q 1u
+#define VL_T_K 2u
+#define VL_T_V 4u
+#define VL_T_O 8u      /* attention.output.dense */
+#define VL_T_FC1 16u   /* intermediate.dense     */
+#define VL_T_FC2 32u   /* output.dense           */
+
+typedef struct vl_config {
+    /* architecture: HF ViTConfig as built by create_vit_model, Utils.py:84-90 */
+    int32_t image_size;   /* 224 */
+    int32_t patch_size;   /* 16  */
+    int32_t hidden;       /* 768  (multiple of 128; head_dim must be 64) */
+    int32_t layers;       /* 12  */
+    int32_t heads;        /* 12  */
+    int32_t mlp;          /* 3072 (multiple of 128) */
+    int32_t num_labels;   /* #lines of class_mappings.txt, whitebox_attacks.py:88-90 */
+    float   ln_eps;       /* 1e-12 */
+    /* LoRA: LoraConfig(r, lora_alpha, lora_dropout, target_modules), train_loras.py:83-90 */
+    int32_t lora_r;       /* 0 = no adapters */
+    float   lora_alpha;
+    float   lora_dropout; /* applied to the LoRA branch input in train mode only */
+    uint32_t lora_targets;/* VL_T_* bits */
+    int32_t lora_merged;  /* 0: rank-r update fused into the GEMMs as extra K tiles;
+                             1: W' = W + s*B*A folded at vl_lora_commit (merge_and_unload,
+                                eval_compose.py:110) */
+    int32_t reserved[4];
+} vl_config;
+
+typedef struct vl_model vl_model;
+
+const char* vl_version(void);
+const char* vl_last_error(void);
+
+/* create_vit_model(num_classes) + setup_peft_lora(model, rank, alpha, dropout, targets)
+ * (Utils.py:84-90, train_loras.py:79-95).  Allocates the packed frozen weights. */
+int vl_create(const vl_config* cfg, vl_model** out);
+int vl_destroy(vl_model* m);
+
+/* model.load_state_dict(torch.load(path)) (whitebox_attacks.py:94): one call per
+ * state-dict entry, HF-4.55.2 key names ("vit.encoder.layer.3.attention.attention.query.weight",
+ * "classifier.bias", ...).  src = device fp32, contiguous, numel elements. */
+int vl_load_tensor(vl_model* m, const char* name, const float* src, int64_t numel, void* stream);
+
+/* LoRA / classifier master parameters live in ONE flat fp32 buffer (so that the
+ * gradient all-reduce and Adam are single flat operations).
+ * which: 0 = lora_A [r,in], 1 = lora_B [out,r].  target = one VL_T_* bit.
+ * Classifier: layer = -1, which 0 = weight [C,D], 1 = bias [C]. */
+int vl_param_tensor(vl_model* m, int layer, uint32_t target, int which, float** ptr, int64_t* numel);
+int vl_param_flat(vl_model* m, float** ptr, int64_t* numel);
+/* Re-derive the bf16 GEMM operands from the flat master buffer (after loading an
+ * adapter, after an optimiser step, or to merge).  PeftModel.from_pretrained /
+ * merge_and_unload (train_loras.py:419, eval_compose.py:108-110). */
+int vl_lora_commit(vl_model* m, void* stream);
+
+/* mean/std used when normalise != 0 (default: ImageNet constants of get_normalization,
+ * Utils.py:92-93; torchattacks' set_normalization_used(mean, std), whitebox_attacks.py:169). */
+int vl_set_normalization(vl_model* m, const float mean[3], const float std[3]);
+
+/* Workspace: vl_plan returns the bytes needed for batches up to max_batch;
+ * train != 0 additionally keeps what the LoRA weight-gradient needs. */
+int vl_plan(vl_model* m, int max_batch, int train, size_t* bytes);
+int vl_set_workspace(vl_model* m, void* ws, size_t bytes);
+
+/* model(x) -> logits [B, C] fp32  (LogitsModel.forward / get_model_output,
+ * whitebox_attacks.py:13-19,41-48; peft_model.base_model(pixel_values=x).logits,
+ * train_loras.py:310-311).  x = [B,3,S,S] fp32 NCHW.  normalise != 0 applies
+ * (x-mean)/std with the ImageNet constants of get_normalization (Utils.py:92-93)
+ * inside the patch gather (whitebox_attacks.py:26).  train != 0: LoRA dropout on,
+ * activations for vl_backward_lora kept. */
+int vl_forward(vl_model* m, const float* x, int batch, int normalise, int train,
+               float* logits_out, void* stream);
+
+/* F.cross_entropy(logits, labels) mean reduction (whitebox_attacks.py:29,
+ * train_loras.py:313) on the logits of the last vl_forward.  labels int64 [B].
+ * loss_out: 1 float (device). Also stages dLoss/dlogits for the backward calls. */
+int vl_loss_ce(vl_model* m, const int64_t* labels, float* loss_out, void* stream);
+
+/* Supply dLoss/dlogits [B,C] fp32 computed by the caller instead of vl_loss_ce (lets
+ * `criterion(logits, labels).backward()` of train_loras.py:313-314 drive the chain). */
+int vl_set_dlogits(vl_model* m, const float* dlogits, void* stream);
+
+/* One backward pass producing both gradients; either output may be NULL. */
+int vl_backward(vl_model* m, float* grad_x_out, float* flat_grad_out, void* stream);
+
+/* loss.backward() restricted to the input: dLoss/dx [B,3,S,S] fp32 in the space of
+ * the x given to vl_forward (perturbed.grad, whitebox_attacks.py:30-32). */
+int vl_backward_input(vl_model* m, float* grad_x_out, void* stream);
+
+/* loss.backward() restricted to the trainable parameters (train_loras.py:314):
+ * flat_grad_out has the layout of vl_param_flat.  Requires vl_forward(train=1). */
+int vl_backward_lora(vl_model* m, float* flat_grad_out, void* stream);
+
+/* Fused FGSM/PGD update (K10): adv <- clamp(x0 + clamp(adv + alpha*sign(g) - x0, -eps, eps), lo, hi)
+ * FGSM (whitebox_attacks.py:32-36) = one call with x0 == adv, alpha = eps. n elements. */
+int vl_pgd_step(float* adv, const float* x0, const float* grad, float eps, float alpha,
+                float lo, float hi, int64_t n, void* stream);
+/* PGD random start (K11): adv = clamp(x0 + U(-eps,eps), lo, hi), counter-based RNG. */
+int vl_pgd_init(float* adv, const float* x0, float eps, float lo, float hi, uint64_t seed,
+                int64_t n, void* stream);
+
+/* torchattacks.PGD(model, eps, alpha, steps, random_start)(images, labels)
+ * (whitebox_attacks.py:112-113,170).  One iteration (forward, CE, backward-to-input,
+ * fused step) is captured once into a hipGraph and replayed `steps` times.
+ * x0, adv_out: [B,3,S,S] fp32 in [0,1]; adv_out may not alias x0. */
+int vl_pgd_attack(vl_model* m, const float* x0, const int64_t* labels, int batch,
+                  float eps, float alpha, int steps, int random_start, uint64_t seed,
+                  float* adv_out, void* stream);
+
+/* optimizer.step() of torch.optim.Adam(lr, betas, eps) (train_loras.py:284,315) on a
+ * flat buffer; t = 1-based step count. */
+int vl_adam_step(float* param, const float* grad, float* m1, float* m2, float lr, float b1,
+                 float b2, float eps, int t, int64_t n, void* stream);
+
+/* save_images quantisation (Utils.py:108-112): clamp(0,1)*255 -> uint8 truncation,
+ * CHW float -> HWC bytes. */
+int vl_quantize_u8(const float* images, uint8_t* out_hwc, int batch, int channels, int height,
+                   int width, void* stream);
+
+/* dst[b,c,:,:] = src[b,c,:,:] * scale[c] + shift[c]  (torchattacks' normalize /
+ * inverse_normalize around the attack when set_normalization_used was called). dst may alias src. */
+int vl_channel_affine(float* dst, const float* src, const float scale[3], const float shift[3],
+                      int batch, int64_t hw, void* stream);
+
+/* Introspection for tests / profiling. */
+int vl_debug_tensor(vl_model* m, const char* what, int layer, void** ptr, int64_t* numel, int* dtype);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITLORA_H */

@@ -232,8 +232,9 @@ def lora_linear(x, W, b, ab, scaling, sim=False, drop_mask=None):
 
 def vit_forward(w: Dict[str, torch.Tensor], cfg: OracleConfig, x_norm: torch.Tensor,
                 lora: Optional[OracleLora] = None, sim_bf16: bool = False,
-                return_hidden: bool = False):
-    """logits [B, C] from already-normalised pixels [B, 3, H, W]."""
+                return_hidden: bool = False, trace: Optional[dict] = None):
+    """logits [B, C] from already-normalised pixels [B, 3, H, W].  ``trace`` (a dict)
+    receives the intermediate tensors the HIP path exposes through vl_debug_tensor."""
     sim = sim_bf16
     B = x_norm.shape[0]
     D, H, dh, N = cfg.hidden, cfg.heads, cfg.head_dim, cfg.tokens
@@ -246,6 +247,8 @@ def vit_forward(w: Dict[str, torch.Tensor], cfg: OracleConfig, x_norm: torch.Ten
     emb = F.linear(patches, _wq(Wpe, sim), w["vit.embeddings.patch_embeddings.projection.bias"])
     x = torch.cat([w["vit.embeddings.cls_token"].expand(B, -1, -1), emb], dim=1)
     x = x + w["vit.embeddings.position_embeddings"]
+    if trace is not None:
+        trace["xs0"] = x.detach()
     sc = lora.scaling if lora is not None else 0.0
 
     def ab(i, short):
@@ -266,11 +269,18 @@ def vit_forward(w: Dict[str, torch.Tensor], cfg: OracleConfig, x_norm: torch.Ten
         s = torch.matmul(q, k_.transpose(2, 3)) * (dh ** -0.5)
         pr = _rb(torch.softmax(s, dim=-1), sim)
         ctx = _rb(torch.matmul(pr, v).transpose(1, 2).reshape(B, N, D), sim)
+        if trace is not None:
+            trace[f"qkv{i}"] = torch.cat([t_.transpose(1, 2).reshape(B, N, D) for t_ in (q, k_, v)], dim=-1).detach()
+            trace[f"ctx{i}"] = ctx.detach()
         x = x + lin("o", ctx)
+        if trace is not None:
+            trace[f"xs{2 * i + 1}"] = x.detach()
         h2 = _rb(F.layer_norm(x, (D,), w[p + "layernorm_after.weight"],
                               w[p + "layernorm_after.bias"], cfg.ln_eps), sim)
         a = _rb(F.gelu(lin("fc1", h2)), sim)          # exact erf GELU (hidden_act="gelu")
         x = x + lin("fc2", a)
+        if trace is not None:
+            trace[f"xs{2 * i + 2}"] = x.detach()
     xf = F.layer_norm(x[:, 0], (D,), w["vit.layernorm.weight"], w["vit.layernorm.bias"], cfg.ln_eps)
     logits = F.linear(xf, w["classifier.weight"], w["classifier.bias"])
     return (logits, x) if return_hidden else logits

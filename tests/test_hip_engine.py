@@ -1,0 +1,204 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Two oracles modes are used:
+  * sim_bf16 = the oracle with bf16 round trips where the kernels store bf16 -> tight
+    tolerances that check the kernels' logic (indexing, masking, softmax, LoRA fusion);
+  * fp32     = the reference arithmetic -> the north-star bf16 tolerance (1e-2 relative).
+"""
+import pytest
+import torch
+
+from helpers import O, make_case, make_engine, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL_SIM = 4e-3      # HIP bf16 path vs bf16-simulating oracle (accumulation order only)
+TOL_FP32 = 1e-2     # north_star: 1e-2 relative for the bf16 path vs the fp32 reference path
+
+
+def _trace(cfg, w, lora, x_norm, sim):
+    tr = {}
+    logits = O.vit_forward(w, cfg, x_norm, lora, sim_bf16=sim, trace=tr)
+    tr["logits"] = logits
+    return tr
+
+
+@pytest.mark.parametrize("image_size,batch", [(64, 4), (224, 3)])
+@pytest.mark.parametrize("with_lora", [False, True])
+def test_forward_stagewise(image_size, batch, with_lora):
+    cfg, w, lora, x, y = make_case(image_size=image_size, batch=batch, r=8 if with_lora else 0)
+    eng = make_engine(cfg, w, lora)
+    xn = O.normalise(x)
+    logits = eng.forward(xn.cuda(), normalise=False)
+    torch.cuda.synchronize()
+    tr = _trace(cfg, w, lora, xn, sim=True)
+    B, T, D = batch, cfg.tokens, cfg.hidden
+    report = []
+    for i in range(2 * cfg.layers + 1):
+        got = eng.debug_tensor("xs", i).float().cpu().view(B, T, D)
+        report.append((f"xs{i}", rel_l2(got, tr[f"xs{i}"])))
+    for l in range(cfg.layers):
+        got = eng.debug_tensor("qkv", l).float().cpu().view(B, T, 3 * D)
+        report.append((f"qkv{l}", rel_l2(got, tr[f"qkv{l}"])))
+        got = eng.debug_tensor("ctx", l).float().cpu().view(B, T, D)
+        report.append((f"ctx{l}", rel_l2(got, tr[f"ctx{l}"])))
+    report.append(("logits", rel_l2(logits.cpu(), tr["logits"])))
+    bad = [(n, e) for n, e in report if not (e < TOL_SIM)]
+    assert not bad, f"stages off: {bad}\nall: {report}"
+    # and against the fp32 reference arithmetic
+    ref = O.vit_forward(w, cfg, xn, lora)
+    assert rel_l2(logits.cpu(), ref) < TOL_FP32
+
+
+@pytest.mark.parametrize("image_size,batch", [(64, 4), (224, 3)])
+@pytest.mark.parametrize("with_lora", [False, True])
+def test_loss_and_input_grad(image_size, batch, with_lora):
+    cfg, w, lora, x, y = make_case(image_size=image_size, batch=batch, r=8 if with_lora else 0)
+    eng = make_engine(cfg, w, lora)
+    logits = eng.forward(x.cuda(), normalise=True)
+    loss = eng.loss_ce(y.cuda())
+    gx, _ = eng.backward(True, False, tuple(x.shape))
+    torch.cuda.synchronize()
+    l_sim, g_sim, _ = O.loss_and_input_grad(w, cfg, x, y, lora, sim_bf16=True)
+    l_ref, g_ref, lg_ref = O.loss_and_input_grad(w, cfg, x, y, lora)
+    assert abs(loss.item() - l_sim.item()) < 2e-3 * max(1.0, abs(l_sim.item()))
+    e_sim, e_ref = rel_l2(gx.cpu(), g_sim), rel_l2(gx.cpu(), g_ref)
+    assert e_sim < 8e-3, (e_sim, e_ref)
+    assert e_ref < 2e-2, (e_sim, e_ref)   # input gradient through 2x bf16 chains; logits/loss hold 1e-2
+    assert rel_l2(logits.cpu(), lg_ref) < TOL_FP32
+    # sign agreement where the gradient is not in the rounding noise
+    big = g_ref.abs() > 0.05 * g_ref.abs().mean()
+    agree = (torch.sign(gx.cpu())[big] == torch.sign(g_ref)[big]).float().mean().item()
+    assert agree > 0.97, agree
+
+
+def test_unnormalised_forward_equals_normalised_input():
+    cfg, w, lora, x, y = make_case(batch=2)
+    eng = make_engine(cfg, w, lora)
+    a = eng.forward(x.cuda(), normalise=True).clone()
+    b = eng.forward(O.normalise(x).cuda(), normalise=False)
+    assert rel_l2(a.cpu(), b.cpu()) < 2e-3
+
+
+def test_merged_matches_fused():
+    cfg, w, lora, x, y = make_case(batch=3)
+    fused = make_engine(cfg, w, lora).forward(x.cuda(), normalise=True).cpu()
+    merged = make_engine(cfg, w, lora, merged=True).forward(x.cuda(), normalise=True).cpu()
+    ref = O.vit_forward(w, cfg, O.normalise(x), lora)
+    assert rel_l2(merged, ref) < TOL_FP32
+    assert rel_l2(fused, merged) < TOL_FP32
+
+
+def test_pgd_step_kernel_bit_exact():
+    torch.manual_seed(0)
+    n = 3 * 224 * 224 * 2 + 3
+    x0 = torch.rand(n)
+    adv = (x0 + (torch.rand(n) - 0.5) * 0.05).clamp(0, 1)
+    g = torch.randn(n)
+    g[::7] = 0.0
+    g[1::11] = 1e-30
+    g[2::13] = -1e-38
+    eps, alpha = 8 / 255, 2 / 255
+    want = O.pgd_step(adv, x0, g, eps, alpha)
+    cfg, w, lora, _, _ = make_case(batch=1, r=0)
+    eng = make_engine(cfg, w)
+    a = adv.cuda()
+    eng.pgd_step(a, x0.cuda(), g.cuda(), eps, alpha)
+    assert torch.equal(a.cpu(), want)
+    # FGSM form: x0 == adv, alpha == eps  (whitebox_attacks.py:32-36)
+    a = x0.cuda().clone()
+    eng.pgd_step(a, x0.cuda(), g.cuda(), eps, eps)
+    assert torch.equal(a.cpu(), torch.clamp(x0 + eps * torch.sign(g), 0, 1))
+
+
+def test_pgd_attack_matches_oracle_trajectory():
+    cfg, w, lora, x, y = make_case(batch=4)
+    eng = make_engine(cfg, w, lora)
+    eps, alpha, steps = 8 / 255, 2 / 255, 5
+    adv = eng.pgd_attack(x.cuda(), y.cuda(), eps, alpha, steps, random_start=False).cpu()
+    ref = O.pgd(w, cfg, x, y, eps, alpha, steps, lora)
+    assert (adv - x).abs().max().item() <= eps + 1e-6
+    assert adv.min().item() >= 0 and adv.max().item() <= 1
+    # sign() is discontinuous: compare the decisions, not the floats
+    agree = (torch.sign(adv - x) == torch.sign(ref - x)).float().mean().item()
+    assert agree > 0.90, agree
+    # the attack must be as strong as the oracle's
+    l_hip = O.loss_and_input_grad(w, cfg, adv, y, lora)[0].item()
+    l_ref = O.loss_and_input_grad(w, cfg, ref, y, lora)[0].item()
+    l_clean = O.loss_and_input_grad(w, cfg, x, y, lora)[0].item()
+    assert l_hip > l_clean
+    assert abs(l_hip - l_ref) < 0.05 * abs(l_ref - l_clean) + 1e-3, (l_hip, l_ref, l_clean)
+    # graph replay == eager launches, bit for bit
+    import os
+    os.environ["VITLORA_NO_GRAPH"] = "1"
+    try:
+        eng2 = make_engine(cfg, w, lora)
+        adv2 = eng2.pgd_attack(x.cuda(), y.cuda(), eps, alpha, steps, random_start=False).cpu()
+    finally:
+        os.environ.pop("VITLORA_NO_GRAPH")
+    assert torch.equal(adv, adv2)
+
+
+def test_pgd_random_start_is_seeded_and_bounded():
+    cfg, w, lora, x, y = make_case(batch=2, r=0)
+    eng = make_engine(cfg, w)
+    eps = 8 / 255
+    a = torch.empty_like(x).cuda()
+    b = torch.empty_like(x).cuda()
+    eng.pgd_init(a, x.cuda(), eps, seed=3)
+    eng.pgd_init(b, x.cuda(), eps, seed=3)
+    assert torch.equal(a, b)
+    eng.pgd_init(b, x.cuda(), eps, seed=4)
+    assert not torch.equal(a, b)
+    d = (a.cpu() - x)
+    assert d.abs().max().item() <= eps + 1e-7
+    inside = (x > eps) & (x < 1 - eps)
+    u = d[inside] / eps
+    assert abs(u.mean().item()) < 0.02 and abs(u.std().item() - 3 ** -0.5) < 0.02
+
+
+def test_lora_train_grads():
+    cfg, w, lora, x, y = make_case(batch=4, targets=("q", "k", "v", "o", "fc1", "fc2"))
+    eng = make_engine(cfg, w, lora)
+    xn = O.normalise(x)
+    logits = eng.forward(xn.cuda(), normalise=False, train=True)
+    loss = eng.loss_ce(y.cuda())
+    _, gp = eng.backward(False, True)
+    torch.cuda.synchronize()
+    l_ref, lg_ref, grads = O.lora_train_grads(w, cfg, xn, y, lora)
+    l_sim, _, grads_sim = O.lora_train_grads(w, cfg, xn, y, lora, sim_bf16=True)
+    assert abs(loss.item() - l_ref.item()) < 1e-2 * abs(l_ref.item())
+    # walk the flat layout: same order as the library (layer, target) -> A, B ; classifier
+    flat = eng.flat
+    base = flat.data_ptr()
+    worst = 0.0
+    for i in range(cfg.layers):
+        for t in lora.targets:
+            for which in ("A", "B"):
+                v = eng.param(i, t, which)
+                off = (v.data_ptr() - base) // 4
+                got = gp[off:off + v.numel()].view(v.shape).cpu()
+                e_sim = rel_l2(got, grads_sim[(which, i, t)])
+                e_ref = rel_l2(got, grads[(which, i, t)])
+                worst = max(worst, e_sim)
+                assert e_sim < 1.5e-2 and e_ref < 3e-2, (i, t, which, e_sim, e_ref)
+    for which in ("weight", "bias"):
+        v = eng.param(-1, "", which)
+        off = (v.data_ptr() - base) // 4
+        got = gp[off:off + v.numel()].view(v.shape).cpu()
+        assert rel_l2(got, grads[("cls", which)]) < 1e-2
+
+
+def test_adam_and_quantiser():
+    torch.manual_seed(1)
+    cfg, w, lora, x, y = make_case(batch=1, r=0)
+    eng = make_engine(cfg, w)
+    p0 = torch.randn(5000)
+    p, m, v = p0.cuda().clone(), torch.zeros(5000).cuda(), torch.zeros(5000).cuda()
+    q, qm, qv = p0.clone(), torch.zeros(5000), torch.zeros(5000)
+    for t in range(1, 4):
+        g = torch.randn(5000)
+        eng.adam_step(p, g.cuda(), m, v, 1e-4, 0.9, 0.999, 1e-8, t)
+        q, qm, qv = O.adam_step(q, g, qm, qv, t)
+    assert torch.allclose(p.cpu(), q, rtol=1e-5, atol=1e-7)
+    img = torch.rand(2, 3, 17, 19) * 1.2 - 0.1
+    assert torch.equal(eng.quantize_u8(img.cuda()).cpu(), O.save_images_quant(img))
