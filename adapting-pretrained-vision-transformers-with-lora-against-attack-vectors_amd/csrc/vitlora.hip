@@ -101,6 +101,7 @@ struct vl_model {
     int cur_B = 0, cur_norm = 0, cur_train = 0, have_loss = 0;
     // PGD graph cache
     hipGraphExec_t graph_exec = nullptr;
+    hipStream_t cap_stream = nullptr;
     struct { const void* x0; const void* labels; void* adv; int B; float eps, alpha; } gkey = {};
     int use_graph = 1;
     int plan_batch = 0, plan_train = 0;
@@ -259,6 +260,7 @@ int vl_create(const vl_config* cfg, vl_model** out) {
 int vl_destroy(vl_model* m) {
     if (!m) return VL_OK;
     if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+    if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     for (void* p : m->allocs) (void)hipFree(p);
     delete m;
     return VL_OK;
@@ -668,9 +670,12 @@ int vl_pgd_attack(vl_model* m, const float* x0, const int64_t* labels, int batch
     if (!hit) {
         if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
         hipGraph_t graph = nullptr;
-        HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        int rc = pgd_iteration(m, x0, labels, batch, eps, alpha, adv_out, s);
-        hipError_t e = hipStreamEndCapture(s, &graph);
+        // capture on a private stream (the caller's may be the legacy default stream, which cannot
+        // capture); nothing executes during capture, the graph is launched on the caller's stream.
+        if (!m->cap_stream) HIPCHK(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
+        int rc = pgd_iteration(m, x0, labels, batch, eps, alpha, adv_out, m->cap_stream);
+        hipError_t e = hipStreamEndCapture(m->cap_stream, &graph);
         if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         if (e != hipSuccess) return fail(VL_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
         e = hipGraphInstantiate(&m->graph_exec, graph, nullptr, nullptr, 0);
