@@ -13,6 +13,7 @@
 // directly the B operand of the next product (k order permuted identically on both operands),
 // and every per-row quantity (max, sum, LSE, delta) is lane-local.
 #include "kernels.h"
+#include "prof.h"
 
 namespace {
 
@@ -323,6 +324,7 @@ void attention_init() {
 }
 
 int k_attention_fwd(const bf16* qkv, bf16* ctx, float* lse2, int B, int T, int H, int D, hipStream_t s) {
+    ProfScope prof_("attn_fwd_kernel", 4.0 * B * H * (double)T * T * HD, (double)B * T * D * 8.0, s);
     const float sl = 0.125f * 1.4426950408889634f;
     if (T <= 32) hipLaunchKernelGGL((attn_fwd_kernel<2>), dim3(B * H), dim3(256), 0, s, qkv, ctx, lse2, T, H, D, sl);
     else if (T <= 224) hipLaunchKernelGGL((attn_fwd_kernel<14>), dim3(B * H), dim3(256), 0, s, qkv, ctx, lse2, T, H, D, sl);
@@ -332,6 +334,7 @@ int k_attention_fwd(const bf16* qkv, bf16* ctx, float* lse2, int B, int T, int H
 
 int k_attention_bwd(const bf16* qkv, const bf16* ctx, const bf16* dctx, const float* lse2, bf16* dqkv, int B, int T,
                     int H, int D, hipStream_t s) {
+    ProfScope prof_("attn_bwd_kernel", 10.0 * B * H * (double)T * T * HD, (double)B * T * D * 16.0, s);
     if (T <= 32) launch_bwd<2>(qkv, ctx, dctx, lse2, dqkv, B, T, H, D, s);
     else if (T <= 224) launch_bwd<14>(qkv, ctx, dctx, lse2, dqkv, B, T, H, D, s);
     else return -1;

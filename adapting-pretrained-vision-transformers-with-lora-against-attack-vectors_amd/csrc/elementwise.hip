@@ -3,6 +3,7 @@
 // flat Adam (K12), the save_images quantiser and the weight packers.
 // Every kernel moves 16 bytes per lane wherever the layout allows it.
 #include "kernels.h"
+#include "prof.h"
 
 namespace {
 
@@ -406,6 +407,7 @@ static inline int nblk(int64_t n, int t, int cap = 1 << 20) {
 
 void k_patch_gather(const float* x, bf16* out, int B, int S, int P, int normalise, const float* mean,
                     const float* std, hipStream_t s) {
+    ProfScope prof_("patch_gather_kernel", 0.0, (double)B * 3 * S * S * 6.0, s);
     const int G = S / P;
     const int64_t total = (int64_t)B * G * G * (3 * P * P / 8);
     hipLaunchKernelGGL(patch_gather_kernel, dim3(nblk(total, 256, 8192)), dim3(256), 0, s, x, out, B, S, P, G,
@@ -416,6 +418,7 @@ void k_cls_rows(float* x, const float* cls, const float* pos, int B, int T, int 
 }
 void k_layernorm_fwd(const float* x, bf16* h, float* mean, float* rstd, const float* g, const float* b, int M, int D,
                      float eps, hipStream_t s) {
+    ProfScope prof_("layernorm_fwd_kernel", 0.0, (double)M * D * 6.0, s);
     const int nv = (D / 4 + 63) / 64;
     dim3 grid((M + 3) / 4), blk(256);
     switch (nv) {
@@ -427,6 +430,7 @@ void k_layernorm_fwd(const float* x, bf16* h, float* mean, float* rstd, const fl
 }
 void k_layernorm_bwd(const bf16* dh, const float* x, const float* mean, const float* rstd, const float* g,
                      const float* dres, float* dx, bf16* dx_bf, int M, int D, hipStream_t s) {
+    ProfScope prof_("layernorm_bwd_kernel", 0.0, (double)M * D * 16.0, s);
     const int nv = (D / 4 + 63) / 64;
     dim3 grid((M + 3) / 4), blk(256);
     switch (nv) {
@@ -438,6 +442,7 @@ void k_layernorm_bwd(const bf16* dh, const float* x, const float* mean, const fl
 }
 void k_head_fwd(const float* x, int B, int T, int D, int C, float eps, const float* g, const float* b, const float* Wc,
                 const float* bc, float* xhat, float* xf, float* rstd, float* logits, hipStream_t s) {
+    ProfScope prof_("head_fwd_kernel", 0.0, (double)B * D * 4.0, s);
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), (D + 4) * sizeof(float), s, x, T, D, C, eps, g, b, Wc, bc,
                        xhat, xf, rstd, logits);
 }
@@ -446,6 +451,7 @@ void k_ce_loss(const float* logits, const int64_t* labels, int B, int C, float* 
 }
 void k_head_bwd(const float* dlogits, const float* Wc, const float* g, const float* xhat, const float* rstd, int B,
                 int T, int D, int C, float* dx, bf16* dx_bf, hipStream_t s) {
+    ProfScope prof_("head_bwd_kernel", 0.0, (double)B * D * 6.0, s);
     hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), (D + 4) * sizeof(float), s, dlogits, Wc, g, xhat, rstd, T,
                        D, C, dx, dx_bf);
 }
@@ -455,15 +461,18 @@ void k_classifier_grad(const float* dlogits, const float* xf, int B, int D, int 
 }
 void k_pgd_step(float* adv, const float* x0, const float* grad, float eps, float alpha, float lo, float hi, int64_t n,
                 hipStream_t s) {
+    ProfScope prof_("pgd_step_kernel", 0.0, (double)n * 16.0, s);
     const int64_t n4 = n / 4;
     hipLaunchKernelGGL(pgd_step_kernel, dim3(nblk(n4 > 0 ? n4 : 1, 256, 2048)), dim3(256), 0, s, adv, x0, grad, eps,
                        alpha, lo, hi, n4, n);
 }
 void k_pgd_init(float* adv, const float* x0, float eps, float lo, float hi, uint64_t seed, int64_t n, hipStream_t s) {
+    ProfScope prof_("pgd_init_kernel", 0.0, (double)n * 8.0, s);
     hipLaunchKernelGGL(pgd_init_kernel, dim3(nblk(n, 256, 4096)), dim3(256), 0, s, adv, x0, eps, lo, hi, seed, n);
 }
 void k_adam(float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps, int t, int64_t n,
             hipStream_t s) {
+    ProfScope prof_("adam_kernel", 0.0, (double)n * 28.0, s);
     const float bc1 = 1.f - powf(b1, (float)t);
     const float sqrt_bc2 = sqrtf(1.f - powf(b2, (float)t));
     hipLaunchKernelGGL(adam_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, p, g, m, v, lr, b1, b2, eps, bc1, sqrt_bc2, n);

@@ -31,6 +31,8 @@ struct GemmArgs {
     // A-row gather for the patch-embedding backward: GEMM row m = b*patches + p reads A row
     // b*tokens + 1 + p (the non-CLS rows of the token-major gradient); 0 = off
     int a_gather;
+    // algorithmic sizes for profiling (0 = use N / K2): true LoRA rank columns, not the padded ones
+    int n_algo, k2_algo;
 };
 
 // bn = 128 (default) or 64 (skinny LoRA-down GEMMs)

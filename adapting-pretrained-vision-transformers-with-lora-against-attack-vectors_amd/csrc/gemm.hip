@@ -8,6 +8,8 @@
 // ds_read_b128 fragment reads), one barrier per K step, 16x16x32 MFMA with the operands
 // swapped so that each lane owns 4 consecutive output columns (8/16-byte stores).
 #include "gemm.h"
+#include "prof.h"
+#include <cstdio>
 
 namespace {
 
@@ -195,6 +197,10 @@ void gemm_init() {
 }
 
 void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
+    char name[64];
+    snprintf(name, sizeof name, "gemm_nt_kernel<%d, %d>", bn == 64 ? 64 : 128, epi);
+    const double mv = a.Mvalid ? a.Mvalid : a.M;
+    ProfScope prof_(name, 2.0 * mv * (a.n_algo ? a.n_algo : a.N) * (a.K1 + (a.k2_algo ? a.k2_algo : a.K2)), 0.0, s);
     if (bn == 64) {
         switch (epi) {
             case EPI_STORE_BF16: launch_t<64, EPI_STORE_BF16>(a, s); return;

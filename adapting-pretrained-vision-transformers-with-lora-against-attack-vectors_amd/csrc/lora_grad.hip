@@ -4,6 +4,7 @@
 // Generic form: Out[i][j] = scale * sum_m L[m][i] * R[m][j] over the M token rows.
 // v1: LDS-staged VALU kernel, M split over workgroups, fp32 atomics into a zeroed output.
 #include "kernels.h"
+#include "prof.h"
 
 namespace {
 
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(const bf16* __restrict_
 
 void k_lora_wgrad(const bf16* L, int ldl, int ncl, const bf16* R, int ldr, int ncr, int M, float scale, float* out,
                   int ldo, int transpose_out, float* /*scratch*/, hipStream_t s) {
+    ProfScope prof_("lora_wgrad_kernel", 2.0 * M * (double)ncl * ncr, 0.0, s);
     dim3 grid((M + MC - 1) / MC, (ncl + 63) / 64, (ncr + 63) / 64);
     hipLaunchKernelGGL(lora_wgrad_kernel, grid, dim3(256), 0, s, L, ldl, ncl, R, ldr, ncr, M, scale, out, ldo,
                        transpose_out);

@@ -1,0 +1,36 @@
+// Optional per-launch timing with HIP events on the launch stream (vl_profile_begin/_report).
+// Off by default: a scope costs one pointer test.  Never active inside a graph capture.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+struct ProfRecord {
+    std::string name;
+    double flops, bytes;
+    hipEvent_t e0, e1;
+};
+
+struct Profiler {
+    std::vector<ProfRecord> recs;
+};
+
+extern Profiler* g_prof;   // defined in vitlora.hip; non-null only between begin and report
+
+struct ProfScope {
+    hipStream_t s;
+    hipEvent_t e1 = nullptr;
+    ProfScope(const char* name, double flops, double bytes, hipStream_t stream) : s(stream) {
+        if (!g_prof) return;
+        ProfRecord r;
+        r.name = name; r.flops = flops; r.bytes = bytes;
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+        (void)hipEventRecord(r.e0, s);
+        e1 = r.e1;
+        g_prof->recs.push_back(r);
+    }
+    ~ProfScope() {
+        if (e1) (void)hipEventRecord(e1, s);
+    }
+};

@@ -11,6 +11,9 @@
 
 #include "../../include/vitlora.h"
 #include "kernels.h"
+#include "prof.h"
+
+Profiler* g_prof = nullptr;
 
 namespace {
 
@@ -98,7 +101,7 @@ struct vl_model {
     int64_t flat_n = 0, cls_w_off = 0, cls_b_off = 0;
     Workspace ws;
     // state of the last forward
-    int cur_B = 0, cur_norm = 0, cur_train = 0, have_loss = 0;
+    int cur_B = 0, cur_M = 0, cur_norm = 0, cur_train = 0, have_loss = 0;
     // PGD graph cache
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t cap_stream = nullptr;
@@ -137,9 +140,11 @@ void add_ext(GemmArgs& g, const bf16* A2, int lda2, const bf16* W2, int ldw2, in
 void linear_fwd(vl_model* m, const Linear& ln, const bf16* x, bf16* t, int Mpad, GemmArgs g, int epi, hipStream_t s) {
     g.A1 = x; g.lda1 = ln.in; g.W1 = ln.W; g.ldw1 = ln.in; g.K1 = ln.in;
     g.M = Mpad; g.N = ln.out; g.bias = ln.bias;
-    if (!g.Mvalid) g.Mvalid = Mpad;
+    g.Mvalid = m->cur_M;
     if (ln.kext && !m->cfg.lora_merged) {
         GemmArgs d = gemm_args(x, ln.in, ln.Ad, ln.in, ln.in, Mpad, ln.kext);
+        d.Mvalid = m->cur_M; d.n_algo = m->r * (int)ln.slots.size();
+        g.k2_algo = m->r;      // each output column sees r LoRA columns
         d.C = t; d.ldc = ln.kext;
         launch_gemm(d, EPI_STORE_BF16, 64, s);
         add_ext(g, t, ln.kext, ln.Bu, ln.kext, ln.kext);
@@ -151,9 +156,12 @@ void linear_fwd(vl_model* m, const Linear& ln, const bf16* x, bf16* t, int Mpad,
 void linear_dgrad(vl_model* m, const Linear& ln, const bf16* dy, bf16* u, int Mpad, GemmArgs g, int epi, hipStream_t s) {
     g.A1 = dy; g.lda1 = ln.out; g.W1 = ln.WT; g.ldw1 = ln.out; g.K1 = ln.out;
     g.M = Mpad; g.N = ln.in; g.bias = nullptr;
-    if (!g.Mvalid) g.Mvalid = Mpad;
+    g.Mvalid = m->cur_M;
     if (ln.kext && !m->cfg.lora_merged) {
         GemmArgs d = gemm_args(dy, ln.out, ln.Bd, ln.out, ln.out, Mpad, ln.kext);
+        // u = dy B: each of the r*slots columns sums over its own module's `out` rows only
+        d.Mvalid = m->cur_M; d.n_algo = m->r; 
+        g.k2_algo = m->r * (int)ln.slots.size();
         d.C = u; d.ldc = ln.kext;
         launch_gemm(d, EPI_STORE_BF16, 64, s);
         add_ext(g, u, ln.kext, ln.Au, ln.kext, ln.kext);
@@ -461,6 +469,7 @@ static int forward_impl(vl_model* m, const float* x, int B, int normalise, int t
     const int D = m->D, L = m->L, T = m->T;
     const int Mpad = (int)round_up((int64_t)B * T, 128), Mppad = (int)round_up((int64_t)B * m->NP, 128);
     const int M = B * T;
+    m->cur_M = M;
     k_patch_gather(x, w.patches, B, m->S, m->P, normalise, m->mean, m->stdv, s);
     {
         GemmArgs g = gemm_args(w.patches, m->PK, m->Wpe, m->PK, m->PK, Mppad, D);
@@ -658,7 +667,7 @@ int vl_pgd_attack(vl_model* m, const float* x0, const int64_t* labels, int batch
     if (random_start) k_pgd_init(adv_out, x0, eps, 0.f, 1.f, seed, n, s);
     else HIPCHK(hipMemcpyAsync(adv_out, x0, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (steps <= 0) return VL_OK;
-    if (!m->use_graph) {
+    if (!m->use_graph || g_prof) {
         for (int i = 0; i < steps; ++i) {
             int rc = pgd_iteration(m, x0, labels, batch, eps, alpha, adv_out, s);
             if (rc) return rc;
@@ -697,6 +706,45 @@ int vl_adam_step(float* param, const float* grad, float* m1, float* m2, float lr
 int vl_quantize_u8(const float* images, uint8_t* out_hwc, int batch, int channels, int height, int width, void* stream) {
     if (!images || !out_hwc) return fail(VL_ERR_ARG, "null argument");
     k_quantize(images, out_hwc, batch, channels, height, width, (hipStream_t)stream);
+    return VL_OK;
+}
+
+// ---- profiling -------------------------------------------------------------------------------
+int vl_profile_begin(void) {
+    if (g_prof) return fail(VL_ERR_STATE, "profile already active");
+    g_prof = new Profiler();
+    return VL_OK;
+}
+
+// Synchronises the device, aggregates per kernel name and writes one JSON object:
+// {"name": {"n": launches, "ms": total_ms, "flops": total, "bytes": total}, ...}
+int vl_profile_report(char* buf, size_t cap) {
+    if (!g_prof) return fail(VL_ERR_STATE, "profile not active");
+    Profiler* p = g_prof;
+    g_prof = nullptr;
+    if (hipDeviceSynchronize() != hipSuccess) { delete p; return fail(VL_ERR_HIP, "hipDeviceSynchronize failed"); }
+    struct Agg { std::string name; int n; double ms, flops, bytes; };
+    std::vector<Agg> agg;
+    for (ProfRecord& r : p->recs) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+        Agg* a = nullptr;
+        for (Agg& x : agg) if (x.name == r.name) { a = &x; break; }
+        if (!a) { agg.push_back({r.name, 0, 0, 0, 0}); a = &agg.back(); }
+        a->n++; a->ms += ms; a->flops += r.flops; a->bytes += r.bytes;
+    }
+    delete p;
+    std::string out = "{";
+    for (size_t i = 0; i < agg.size(); ++i) {
+        char line[256];
+        snprintf(line, sizeof line, "%s\"%s\": {\"n\": %d, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
+                 i ? ", " : "", agg[i].name.c_str(), agg[i].n, agg[i].ms, agg[i].flops, agg[i].bytes);
+        out += line;
+    }
+    out += "}";
+    if (!buf || cap < out.size() + 1) return fail(VL_ERR_ARG, "buffer too small (%zu needed)", out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
     return VL_OK;
 }
 

@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark: adversarial images/sec, PGD-20, ViT-B/16 + LoRA r=8, batch 256 per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one batch: a full PGD-20 attack
+(random start, then 20 x {forward, CE, backward-to-input, fused sign/project step}, each
+iteration one hipGraph launch) on 256 synthetic 224x224x3 images that are already resident
+in HBM.  Image batches shard over ranks (weak scaling, no data-path collective; the frozen
+backbone and the adapters are replicated).  Rank 0 prints ONE JSON line.
+
+Extra objects in that line:
+  roofline      the dominant kernel, timed live with HIP events on the launch stream
+                (vl_profile_begin/_report, include/vitlora.h) against the gfx950 dense bf16
+                MFMA peak; plus `path` = whole-path algorithmic FLOP/s and `pgd_step` =
+                the HBM-bound elementwise kernel against the 8 TB/s HBM peak.
+  cpu_baseline  the CPU oracle (oracle/, a torch restatement of the reference path) timed on
+                this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "adapting-pretrained-vision-transformers-with-lora-against-attack-vectors_amd"
+
+PEAK_BF16_DENSE = 2.5e15      # FLOP/s, MI355X_MICROARCH.md chip table (dense, no sparsity)
+PEAK_HBM = 8.0e12             # B/s
+
+EPS, ALPHA = 8 / 255, 2 / 255
+TARGETS = ("q", "k", "v", "o", "fc2")    # ["query","key","value","output.dense"], train_loras.py:81
+
+
+def algorithmic_flops_per_image_step(arch, r, targets):
+    """fwd + bwd-to-input FLOPs of one PGD iteration for one image (2 FLOP per MAC), the
+    accounting of SURVEY.md 8(d) / BASELINE.md section 3."""
+    D, M, T, H = arch.hidden, arch.mlp, arch.tokens, arch.heads
+    NP, PK = T - 1, 3 * arch.patch_size ** 2
+    lin = 2 * T * (4 * D * D + 2 * D * M) * arch.layers
+    attn = 4 * H * T * T * (D // H) * arch.layers
+    pe = 2 * NP * PK * D
+    lora = 0
+    for t in targets:
+        o, k = (M, D) if t == "fc1" else (D, M) if t == "fc2" else (D, D)
+        lora += 2 * T * r * (o + k)
+    lora *= arch.layers
+    fwd = lin + attn + pe + lora
+    bwd = lin + 2.0 * attn + pe + lora      # dgrad only; attention x2 as BASELINE.md section 3 counts it
+    return fwd + bwd
+
+
+T_START = time.perf_counter()
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T_START:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return int(os.environ.get("BENCH_CPU_CORES", min(n, 16)))   # a 1-GPU box's CPU share is 16
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--pgd-steps", type=int, default=20)
+    ap.add_argument("--rank", type=int, default=8, help="LoRA rank")
+    ap.add_argument("--merged", action="store_true", help="fold LoRA into W (merge_and_unload) instead of fusing")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+
+    P = importlib.import_module(PKG)
+    arch = P.ArchConfig(num_labels=21)
+    spec = P.LoraSpec(r=args.rank, alpha=16.0, dropout=0.0, targets=TARGETS, merged=args.merged)
+    eng = P.Engine(arch, spec, device=dev)
+    syn = importlib.import_module(PKG + ".synthetic")
+    eng.load_state_dict(syn.random_state_dict(arch, seed=0))
+    for (i, t), (A, Bm) in syn.random_lora(arch, args.rank, TARGETS, seed=1).items():
+        eng.param(i, t, "A").copy_(A)
+        eng.param(i, t, "B").copy_(Bm)
+    eng.commit()
+    log("weights loaded")
+    x, y = syn.random_batch(arch, args.batch, seed=100 + rank)
+    x, y = x.to(dev), y.to(dev)
+    adv = torch.empty_like(x)
+
+    def step(seed):
+        eng.pgd_attack(x, y, EPS, ALPHA, args.pgd_steps, random_start=True, seed=seed, out=adv)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(2 + i)
+        torch.cuda.synchronize()
+        log(f"warmup {i} done")
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(2 + i)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    imgs = world * args.batch * args.steps
+    value = imgs / dt
+    if rank == 0:
+        log(f"timed region: {dt:.3f} s for {args.steps} steps -> {value:.1f} img/s")
+    flops_img_step = algorithmic_flops_per_image_step(arch, args.rank, TARGETS)
+
+    out = {
+        "metric": "adversarial images/sec (PGD-20, ViT-B/16+LoRA r=8, bs256)",
+        "value": value, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"PGD-{args.pgd_steps} eps=8/255 alpha=2/255 random_start, ViT-B/16 (21 classes) + LoRA "
+                               f"r={args.rank} on q,k,v,attn-out,fc2 ({'merged' if args.merged else 'fused'}), "
+                               f"batch {args.batch}/GPU of synthetic 224x224x3 in HBM, seeded random-init weights",
+                   "global_batch": world * args.batch, "pgd_steps": args.pgd_steps, "lora_rank": args.rank,
+                   "parallelism": f"dp{world} (batch shards, no data-path collective)"},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        lib = eng.lib
+        P.check(lib.vl_profile_begin(), "vl_profile_begin")
+        eng.pgd_attack(x, y, EPS, ALPHA, 2, random_start=False, out=adv)      # eager, event-bracketed
+        buf = ctypes.create_string_buffer(1 << 16)
+        P.check(lib.vl_profile_report(buf, len(buf)), "vl_profile_report")
+        prof = json.loads(buf.value.decode())
+        log("roofline pass done")
+        tot_ms = sum(v["ms"] for v in prof.values())
+        dom = max((k for k in prof if prof[k]["flops"] > 0), key=lambda k: prof[k]["ms"])
+        d = prof[dom]
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        ps = prof.get("pgd_step_kernel")
+        out["roofline"] = {
+            "bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
+            "frac": ach * 1e12 / PEAK_BF16_DENSE, "traffic": None,
+            "launches": d["n"], "avg_launch_ms": d["ms"] / d["n"], "share_of_step_time": d["ms"] / tot_ms,
+            "path": {"achieved": value * args.pgd_steps * flops_img_step / 1e12, "unit": "TFLOP/s",
+                     "frac": value * args.pgd_steps * flops_img_step / (world * PEAK_BF16_DENSE),
+                     "gflop_per_image_per_pgd_step": flops_img_step / 1e9},
+            "pgd_step": None if not ps else {
+                "bound": "hbm", "achieved": ps["bytes"] / (ps["ms"] * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9,
+                "unit": "GB/s", "frac": ps["bytes"] / (ps["ms"] * 1e-3) / PEAK_HBM, "avg_launch_ms": ps["ms"] / ps["n"]},
+            "kernels_ms_per_pgd_iteration": {k: round(v["ms"] / 2, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+        }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(arch, args)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(arch, args):
+    """The oracle (CPU torch restatement of the reference path) on a bounded sample: a few
+    images x a few of the 20 PGD steps; every step costs the same, so img/s for PGD-20 =
+    images * (steps_done / 20) / seconds."""
+    from oracle import vit_lora_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    log(f"cpu baseline on {cores} threads")
+    cfg = O.OracleConfig(num_labels=arch.num_labels)
+    w = O.init_weights(cfg, seed=0)
+    lora = O.init_lora(cfg, r=args.rank, targets=TARGETS, seed=1)
+    nb, ns = 4, 3
+    g = torch.Generator().manual_seed(100)
+    x = torch.rand(nb, 3, cfg.image_size, cfg.image_size, generator=g)
+    y = torch.randint(0, cfg.num_labels, (nb,), generator=torch.Generator().manual_seed(101))
+    O.pgd(w, cfg, x[:2], y[:2], EPS, ALPHA, 1, lora)          # warm-up
+    log("cpu warm-up done")
+    t0 = time.perf_counter()
+    O.pgd(w, cfg, x, y, EPS, ALPHA, ns, lora)
+    dt = time.perf_counter() - t0
+    return {"value": nb * (ns / args.pgd_steps) / dt, "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": f"{nb} images x {ns} of {args.pgd_steps} PGD steps (fp32, torch CPU), {dt:.1f} s, scaled by steps"}
+
+
+if __name__ == "__main__":
+    main()

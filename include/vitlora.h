@@ -156,6 +156,14 @@ int vl_quantize_u8(const float* images, uint8_t* out_hwc, int batch, int channel
 int vl_channel_affine(float* dst, const float* src, const float scale[3], const float shift[3],
                       int batch, int64_t hw, void* stream);
 
+/* Per-launch timing with HIP events on the launch stream, for bench.py's roofline object.
+ * Between begin and report every kernel launch of this library is bracketed by an event
+ * pair (PGD runs eagerly, not as a graph, while active).  report synchronises the device and
+ * writes a JSON object {"<kernel>": {"n": launches, "ms": total, "flops": algorithmic,
+ * "bytes": algorithmic}, ...} into buf. */
+int vl_profile_begin(void);
+int vl_profile_report(char* buf, size_t cap);
+
 /* Introspection for tests / profiling. */
 int vl_debug_tensor(vl_model* m, const char* what, int layer, void** ptr, int64_t* numel, int* dtype);
 
