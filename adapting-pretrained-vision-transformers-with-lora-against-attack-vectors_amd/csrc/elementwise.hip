@@ -314,6 +314,14 @@ __global__ void pgd_init_kernel(float* __restrict__ adv, const float* __restrict
     }
 }
 
+__global__ void fill_random_bf16_kernel(bf16* __restrict__ dst, size_t n, uint64_t seed) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t r = mix64(seed * 0xD1342543DE82EF95ull + i);
+        dst[i] = f2bf((float)(r >> 40) * (2.0f / 16777216.0f) - 1.0f);
+    }
+}
+
 // K12: torch.optim.Adam single flat update (train_loras.py:284,315)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, float lr, float b1, float b2, float eps, float bc1,
@@ -482,6 +490,9 @@ void k_channel_affine(float* dst, const float* src, const float* scale, const fl
     const int64_t n = (int64_t)B * 3 * hw;
     hipLaunchKernelGGL(channel_affine_kernel, dim3(nblk(n, 256, 4096)), dim3(256), 0, s, dst, src, scale[0], scale[1],
                        scale[2], shift[0], shift[1], shift[2], hw, n);
+}
+void k_fill_random_bf16(bf16* dst, size_t n, uint64_t seed, hipStream_t s) {
+    hipLaunchKernelGGL(fill_random_bf16_kernel, dim3(4096), dim3(256), 0, s, dst, n, seed);
 }
 void k_quantize(const float* img, uint8_t* out, int B, int C, int H, int W, hipStream_t s) {
     const int64_t n = (int64_t)B * C * H * W;

@@ -2,62 +2,25 @@
 // extra K tiles.  Stands in for the cuBLAS/MKL matmuls that HF ViT + peft issue on the
 // reference's hot path (whitebox_attacks.py:27, train_loras.py:310; SURVEY.md K2,K4,K6-K8).
 //
-// v1 structure: 128 x BN x 64 tile, 4 waves (2x2), direct-to-LDS 16-byte loads
-// (global_load_lds_dwordx4) into a double-buffered, XOR-swizzled row-major image
-// (rows of 128 B; 16-byte chunk c of row r stored at chunk c ^ (r & 7): conflict-free
-// ds_read_b128 fragment reads), one barrier per K step, 16x16x32 MFMA with the operands
-// swapped so that each lane owns 4 consecutive output columns (8/16-byte stores).
-#include "gemm.h"
-#include "prof.h"
+// This file: the 128 x BN x 64 kernel (4 waves, 2x2), used for the skinny LoRA-down GEMMs
+// (BN = 64), for small problems and as the fallback of the 256-row kernel in gemm256.hip.
+// Direct-to-LDS 16-byte loads (global_load_lds_dwordx4) into a double-buffered, XOR-swizzled
+// row-major image (rows of 128 B; 16-byte chunk c of row r stored at chunk c ^ (r & 7):
+// conflict-free ds_read_b128 fragment reads), one barrier per K step, 16x16x32 MFMA with the
+// operands swapped so that each lane owns 4 consecutive output columns (8/16-byte stores).
 #include <cstdio>
+
+#include "gemm_epi.h"
+#include "prof.h"
+
+void launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);   // gemm256.hip
+bool gemm256_supports(const GemmArgs& a, int epi);
+void gemm256_init();
 
 namespace {
 
 constexpr int BM = 128;
 constexpr int BK = 64;
-
-template <int EPI>
-__device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, f32x4 v) {
-    if constexpr (EPI == EPI_STORE_BF16) {
-        bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        *(bf16x4*)((bf16*)p.C + (size_t)m * p.ldc + n) = o;
-    } else if constexpr (EPI == EPI_STORE_F32) {
-        *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
-    } else if constexpr (EPI == EPI_RESID_F32) {
-        const f32x4 r = *(const f32x4*)((const float*)p.R + (size_t)m * p.ldr + n);
-        *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v + r;
-    } else if constexpr (EPI == EPI_GELU) {
-        bf16x4 z = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        bf16x4 a = {f2bf(gelu_f(v[0])), f2bf(gelu_f(v[1])), f2bf(gelu_f(v[2])), f2bf(gelu_f(v[3]))};
-        *(bf16x4*)((bf16*)p.C2 + (size_t)m * p.ldc2 + n) = z;
-        *(bf16x4*)((bf16*)p.C + (size_t)m * p.ldc + n) = a;
-    } else if constexpr (EPI == EPI_GELU_BWD) {
-        const bf16x4 z = *(const bf16x4*)((const bf16*)p.R + (size_t)m * p.ldr + n);
-        bf16x4 o;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = f2bf(v[i] * gelu_grad_f(bf2f(z[i])));
-        *(bf16x4*)((bf16*)p.C + (size_t)m * p.ldc + n) = o;
-    } else if constexpr (EPI == EPI_PATCH_FWD) {
-        if (m < p.Mvalid) {
-            const int b = m / p.patches, pi = m - b * p.patches;
-            const f32x4 pe = *(const f32x4*)(p.pos + (size_t)(1 + pi) * p.ldc + n);
-            *(f32x4*)((float*)p.C + ((size_t)b * p.tokens + 1 + pi) * p.ldc + n) = v + pe;
-        }
-    } else if constexpr (EPI == EPI_PATCH_BWD) {
-        if (m < p.Mvalid) {
-            const int b = m / p.patches, pi = m - b * p.patches;
-            const int py = pi / p.grid, px = pi - py * p.grid;
-            const int pp = p.psize * p.psize;
-            const int c = n / pp, rem = n - c * pp;
-            const int ph = rem / p.psize, pw = rem - ph * p.psize;
-            const float s = p.inv_std[c];
-            f32x4 o = {v[0] * s, v[1] * s, v[2] * s, v[3] * s};
-            float* dst = (float*)p.C + (((size_t)b * 3 + c) * p.img + py * p.psize + ph) * p.img +
-                         px * p.psize + pw;
-            *(f32x4*)dst = o;
-        }
-    }
-}
 
 template <int BN, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
@@ -180,6 +143,8 @@ void set_attr() {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
+int g_force_small = -1;
+
 }  // namespace
 
 void gemm_init() {
@@ -193,14 +158,24 @@ void gemm_init() {
     set_attr<128, EPI_PATCH_FWD>();
     set_attr<128, EPI_PATCH_BWD>();
     set_attr<128, EPI_STORE_F32>();
+    gemm256_init();
+    const char* e = getenv("VITLORA_GEMM128");      // A/B switch: force the 128-row kernel
+    g_force_small = (e && e[0] == '1') ? 1 : 0;
     done = true;
 }
 
 void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
-    char name[64];
-    snprintf(name, sizeof name, "gemm_nt_kernel<%d, %d>", bn == 64 ? 64 : 128, epi);
     const double mv = a.Mvalid ? a.Mvalid : a.M;
-    ProfScope prof_(name, 2.0 * mv * (a.n_algo ? a.n_algo : a.N) * (a.K1 + (a.k2_algo ? a.k2_algo : a.K2)), 0.0, s);
+    const double flops = 2.0 * mv * (a.n_algo ? a.n_algo : a.N) * (a.K1 + (a.k2_algo ? a.k2_algo : a.K2));
+    char name[64];
+    if (bn != 64 && g_force_small != 1 && gemm256_supports(a, epi)) {
+        snprintf(name, sizeof name, "gemm256_kernel<%d>", epi);
+        ProfScope prof_(name, flops, 0.0, s);
+        launch_gemm256(a, epi, s);
+        return;
+    }
+    snprintf(name, sizeof name, "gemm_nt_kernel<%d, %d>", bn == 64 ? 64 : 128, epi);
+    ProfScope prof_(name, flops, 0.0, s);
     if (bn == 64) {
         switch (epi) {
             case EPI_STORE_BF16: launch_t<64, EPI_STORE_BF16>(a, s); return;

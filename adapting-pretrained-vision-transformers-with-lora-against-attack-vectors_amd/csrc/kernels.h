@@ -24,6 +24,7 @@ void k_adam(float* p, const float* g, float* m, float* v, float lr, float b1, fl
             hipStream_t s);
 void k_channel_affine(float* dst, const float* src, const float* scale, const float* shift, int B, int64_t hw,
                       hipStream_t s);
+void k_fill_random_bf16(bf16* dst, size_t n, uint64_t seed, hipStream_t s);   // U(-1,1), benchmarks only
 void k_quantize(const float* img, uint8_t* out, int B, int C, int H, int W, hipStream_t s);
 void k_pack_bf16(const float* src, bf16* dst, int rows, int cols, int ldd, int coff, float scale, hipStream_t s);
 void k_pack_bf16_t(const float* src, bf16* dst, int rows, int cols, int ldd, int roff, float scale, hipStream_t s);

@@ -709,6 +709,40 @@ int vl_quantize_u8(const float* images, uint8_t* out_hwc, int batch, int channel
     return VL_OK;
 }
 
+// ---- GEMM micro-benchmark (tools/gemm_sweep.py): random bf16 operands, HIP-event timing -----
+int vl_bench_gemm(int M, int N, int K1, int K2, int epi, int bn, int iters, float* ms_out) {
+    if (M % 128 || N % 64 || K1 % 64 || K2 % 64 || iters <= 0 || !ms_out) return fail(VL_ERR_ARG, "bad argument");
+    gemm_init();
+    bf16 *A = nullptr, *W = nullptr, *A2 = nullptr, *W2 = nullptr, *C = nullptr, *C2 = nullptr;
+    float *R = nullptr, *bias = nullptr;
+    const size_t nA = (size_t)M * K1, nW = (size_t)N * K1, nC = (size_t)M * N;
+    HIPCHK(hipMalloc(&A, nA * 2)); HIPCHK(hipMalloc(&W, nW * 2));
+    HIPCHK(hipMalloc(&A2, (size_t)M * 64 * 2 + 256)); HIPCHK(hipMalloc(&W2, (size_t)N * 64 * 2 + 256));
+    HIPCHK(hipMalloc(&C, nC * 4)); HIPCHK(hipMalloc(&C2, nC * 2)); HIPCHK(hipMalloc(&R, nC * 4));
+    HIPCHK(hipMalloc(&bias, (size_t)N * 4));
+    k_fill_random_bf16(A, nA, 1, 0); k_fill_random_bf16(W, nW, 2, 0);
+    k_fill_random_bf16(A2, (size_t)M * 64, 3, 0); k_fill_random_bf16(W2, (size_t)N * 64, 4, 0);
+    k_fill_random_bf16((bf16*)R, nC * 2, 5, 0); k_fill_random_bf16((bf16*)bias, (size_t)N * 2, 6, 0);
+    GemmArgs g = gemm_args(A, K1, W, K1, K1, M, N);
+    if (K2) add_ext(g, A2, K2, W2, K2, K2);
+    g.bias = bias; g.C = C; g.ldc = N; g.C2 = C2; g.ldc2 = N; g.R = R; g.ldr = N;
+    if (epi == EPI_RESID_F32) g.R = C;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) launch_gemm(g, epi, bn, 0);
+    HIPCHK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) launch_gemm(g, epi, bn, 0);
+    HIPCHK(hipEventRecord(e1, 0));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(A); (void)hipFree(W); (void)hipFree(A2); (void)hipFree(W2); (void)hipFree(C); (void)hipFree(C2);
+    (void)hipFree(R); (void)hipFree(bias);
+    return VL_OK;
+}
+
 // ---- profiling -------------------------------------------------------------------------------
 int vl_profile_begin(void) {
     if (g_prof) return fail(VL_ERR_STATE, "profile already active");
