@@ -66,3 +66,62 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
         }
     }
 }
+
+// 16 consecutive output columns n0..n0+15 of row m held by one lane as v[0..3] (the 256-row
+// kernel permutes the W rows of its LDS image so that a lane's four column tiles are adjacent):
+// 16-byte loads / stores, 64 B (bf16) or 256 B (f32) contiguous per row and lane quad.
+template <int EPI>
+__device__ __forceinline__ void epilogue_row16(const GemmArgs& p, int m, int n0, const f32x4 (&v)[4]) {
+    auto pack8 = [](const f32x4& a, const f32x4& b) {
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[k] = f2bf(a[k]); o[4 + k] = f2bf(b[k]); }
+        return o;
+    };
+    if constexpr (EPI == EPI_STORE_BF16) {
+        bf16* dst = (bf16*)p.C + (size_t)m * p.ldc + n0;
+        *(bf16x8*)dst = pack8(v[0], v[1]);
+        *(bf16x8*)(dst + 8) = pack8(v[2], v[3]);
+    } else if constexpr (EPI == EPI_STORE_F32) {
+        float* dst = (float*)p.C + (size_t)m * p.ldc + n0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(f32x4*)(dst + 4 * q) = v[q];
+    } else if constexpr (EPI == EPI_RESID_F32) {
+        const float* r = (const float*)p.R + (size_t)m * p.ldr + n0;
+        float* dst = (float*)p.C + (size_t)m * p.ldc + n0;
+        f32x4 rv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rv[q] = *(const f32x4*)(r + 4 * q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(f32x4*)(dst + 4 * q) = v[q] + rv[q];
+    } else if constexpr (EPI == EPI_GELU) {
+        f32x4 a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[q][k] = gelu_fast(v[q][k]);
+        bf16* zd = (bf16*)p.C2 + (size_t)m * p.ldc2 + n0;
+        bf16* ad = (bf16*)p.C + (size_t)m * p.ldc + n0;
+        *(bf16x8*)zd = pack8(v[0], v[1]);
+        *(bf16x8*)(zd + 8) = pack8(v[2], v[3]);
+        *(bf16x8*)ad = pack8(a[0], a[1]);
+        *(bf16x8*)(ad + 8) = pack8(a[2], a[3]);
+    } else if constexpr (EPI == EPI_GELU_BWD) {
+        const bf16* zs = (const bf16*)p.R + (size_t)m * p.ldr + n0;
+        const bf16x8 z0 = *(const bf16x8*)zs, z1 = *(const bf16x8*)(zs + 8);
+        f32x4 o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[0][k] = v[0][k] * gelu_grad_fast(bf2f(z0[k]));
+            o[1][k] = v[1][k] * gelu_grad_fast(bf2f(z0[4 + k]));
+            o[2][k] = v[2][k] * gelu_grad_fast(bf2f(z1[k]));
+            o[3][k] = v[3][k] * gelu_grad_fast(bf2f(z1[4 + k]));
+        }
+        bf16* dst = (bf16*)p.C + (size_t)m * p.ldc + n0;
+        *(bf16x8*)dst = pack8(o[0], o[1]);
+        *(bf16x8*)(dst + 8) = pack8(o[2], o[3]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) epilogue_store<EPI>(p, m, n0 + 4 * q, v[q]);
+    }
+}

@@ -13,6 +13,8 @@ lib.vl_bench_gemm.restype = C.c_int
 lib.vl_bench_gemm.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_float)]
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 else None     # e.g. "qkv fwd,plain 3072x768"
+ITERS = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 M = B * 197
 M = (M + 255) // 256 * 256
 EPI = {0: "store_bf16", 1: "resid_f32", 2: "gelu", 3: "gelu_bwd", 6: "store_f32"}
@@ -24,9 +26,11 @@ shapes = [  # (name, N, K1, K2, epi)
 ]
 tot_ms = tot_fl = 0.0
 for name, N, K1, K2, epi in shapes:
+    if ONLY and name not in ONLY:
+        continue
     m = 4096 if name.startswith("square") else M
     ms = C.c_float()
-    rc = lib.vl_bench_gemm(m, N, K1, K2, epi, 128, 20, C.byref(ms))
+    rc = lib.vl_bench_gemm(m, N, K1, K2, epi, 128, ITERS, C.byref(ms))
     if rc:
         print(name, "error", lib.vl_last_error().decode())
         continue
