@@ -13,6 +13,7 @@ enum GemmEpilogue {
     EPI_PATCH_FWD = 4,    // C(f32)[row b*T + 1 + p] = acc + bias + pos[1+p]
     EPI_PATCH_BWD = 5,    // image-layout scatter of d(patches), scaled by 1/std[c]
     EPI_STORE_F32 = 6,    // C(f32) = acc + bias
+    EPI_NONE = 7,         // diagnostic: results kept live, nothing stored (timing of the main loop alone)
 };
 
 struct GemmArgs {

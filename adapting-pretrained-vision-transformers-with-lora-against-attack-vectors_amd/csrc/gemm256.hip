@@ -1,24 +1,27 @@
-// Main GEMM of the path: BM x 256 x 64 tiles (BM = 256 or 128), 8 waves (2 x 4), one
-// PERSISTENT workgroup per CU, 16x16x32 bf16 MFMA, fused epilogues (gemm_epi.h) and the LoRA
-// update as extra K tiles.  C[M,N] = A1 W1^T + A2 W2^T, all operands K-contiguous bf16.
+// Main GEMM of the path: 256 x 256 x 64 tiles, 8 waves (2 x 4), one PERSISTENT workgroup per
+// CU, 16x16x32 bf16 MFMA, fused epilogues (gemm_epi.h) and the LoRA update as extra K tiles.
+// C[M,N] = A1 W1^T + A2 W2^T, all operands K-contiguous bf16.
 //
-// Pipeline (one barrier per phase, four phases per 64-deep K tile, 4 half-tiles in flight):
+// Pipeline (four phases per 64-deep K tile, 4 half-tiles of loads in flight):
 //   * LDS holds two K tiles (2 x (BM + 256) rows of 128 B, XOR-swizzled 16-byte chunks).
 //     Each tile is cut in four "half-tiles": A0/A1 = the rows of every wave's upper / lower
 //     output half, W0/W1 = the rows of every wave's left / right output half.
-//   * phase p of K tile T computes one output quadrant (16 or 8 MFMAs per wave):
+//   * phase p of K tile T computes one output quadrant (16 MFMAs per wave; 8 for BM = 128):
 //       P1 reads A0,W0 -> (0,0)   P2 reads W1 -> (0,1)   P3 reads A1 -> (1,1)   P4 -> (1,0)
 //     and issues ONE half-tile of direct-to-LDS loads (global_load_lds_dwordx4):
 //       P1: W1(T+1)   P2: A1(T+1)   P3: A0(T+2)   P4: W0(T+2)
-//     i.e. a region is overwritten two phases after its last ds_read, so the single barrier
-//     in between orders the write after every wave's reads (WAR), and a half-tile is first
+//     A region is overwritten two phases after its last ds_read (WAR) and a half-tile is first
 //     read one phase after the counted `s_waitcnt vmcnt(N)` + barrier that retires it (RAW).
 //   * N = the loads of the 4 half-tiles issued after the one needed next (2 A + 2 W halves):
-//     never 0 in the steady state, so HBM/L2 latency spans ~4 phases of MFMA work.
-//   * the last two K tiles use their own exact counts (nothing left to prefetch).
+//     never 0 in the steady state; the last two K tiles use their own exact counts.
+//   * every phase is {ds_reads, loads, wait} BARRIER {MFMAs} BARRIER and waves 4-7 (the SIMD
+//     partners of waves 0-3) trail by ONE barrier: while one half of the workgroup runs its
+//     MFMA segment the other half runs its read/load segment, so each SIMD's matrix pipe always
+//     has a wave to run.  The WAR/RAW distances above hold under that half-phase stagger.
 //   * persistent: a workgroup walks output tiles g, g + G, ...; the first 6 half-tiles of the
-//     NEXT output tile are issued before the epilogue of the current one, so their latency
-//     hides under the epilogue's conversions and stores (K is only 12-48 tiles deep here).
+//     NEXT output tile are issued before the epilogue of the current one.
+//   * tail: the rows of the last, partly filled round are cut into 128-row tiles when that
+//     lets them finish in half a round (same kernel, BM = 128 code path).
 //   * W rows are permuted on the way into LDS so that a lane ends up with 16 ADJACENT output
 //     columns: the epilogue moves 16 bytes per lane per instruction.
 #include <type_traits>
@@ -38,249 +41,291 @@ constexpr int BK = 64;
         __builtin_amdgcn_sched_barrier(0);          \
     } while (0)
 
-template <int BM, int EPI>
-__global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BUF = (BM + BN) * BK;     // elements per K-tile buffer: A rows then W rows
-    constexpr int MI = BM / 64;             // 16-row MFMA tiles per output quadrant (m)
-    constexpr int NA = BM / 128;            // load instructions per wave per A half-tile
-    constexpr int NW = 2;                   // ... per W half-tile
-    constexpr int STEADY = 2 * NA + 2 * NW;
-    bf16* sm = (bf16*)smem;
+// VMEM instructions per lane that the epilogue of one output tile is GUARANTEED to issue per
+// 16-row block (a lower bound: conditional ones are not counted).  They sit between the next
+// tile's first loads and its main loop in the in-order vmcnt queue.
+template <int EPI>
+constexpr int epilogue_vmem_per_row() {
+    return EPI == EPI_STORE_BF16 ? 2 : EPI == EPI_STORE_F32 ? 4 : EPI == EPI_RESID_F32 ? 8
+         : EPI == EPI_GELU ? 4 : EPI == EPI_GELU_BWD ? 4 : 0;
+}
+constexpr int clamp63(int v) { return v > 63 ? 63 : v; }
 
+template <int V> using IC = std::integral_constant<int, V>;
+
+// LDS-DMA with explicit operands: 64-bit wave-uniform base in SGPRs + 32-bit per-lane byte offset,
+// LDS destination (wave-uniform) through M0, which is saved and restored around the instruction.
+// hipcc does not count these in its own s_waitcnt bookkeeping; every wait on them below is explicit.
+__device__ __forceinline__ void glds16_sv(const void* sbase, unsigned voff, const void* lds_dst) {
+    const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)lds_dst;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void glds4_sv(const void* sbase, unsigned voff, const void* lds_dst) {
+    const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)lds_dst;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+
+// One launch walks `ntiles` BM-row tiles (row-major over (bm, bn), tile rows starting at bm0)
+// round-robin over the G workgroups.  A GEMM is one BM = 256 launch over full rounds plus, when
+// the tail pays, one BM = 128 launch over the remaining rows (plan_tiles below).
+template <int BM, int EPI>
+__global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntiles, int bm0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* sm = (bf16*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 2, wn = w & 3;
     const int fr = lane & 15, fg = lane >> 4;
     const int lr = lane >> 3, lc = lane & 7;
+    const unsigned csw = (unsigned)((lc ^ lr) * 8);   // swizzled source chunk (row & 7 == lr for every load group)
+    const unsigned wl = (unsigned)(16 * (lr >> 2) + (lr & 3));   // lane part of the permuted W row
     const int tilesN = p.N / BN;
-    const int ntiles = (p.M / BM) * tilesN;
     const int nk1 = p.K1 / BK;
     const int nk = nk1 + p.K2 / BK;
-    const int G = gridDim.x;
+    const int G = gridDim.x, bid = (int)blockIdx.x;
 
-    // tile walked in round `it` by this workgroup.  Workgroups that share an XCD (blockIdx % 8
-    // under round-robin placement; a speed assumption only) take 1/8 of each round's tiles as a
-    // contiguous run, so neighbouring tiles (same A row panel, all of W) meet in one L2.
-    auto tile_of = [&](int it) -> int {
-        const int bid = (int)blockIdx.x;                   // signed: cnt may be <= 0 past the last round
-        const int base = it * G;
-        const int cnt = min(G, ntiles - base);             // tiles in this round
-        if (bid >= cnt) return -1;
-        return base + xcd_remap(bid, cnt);
-    };
-
-    // ---- per-lane load bookkeeping ------------------------------------------------------------
-    // A half h, instruction i: 8-row group g = w*NA + i of the half; the half's rows are
-    // wm'*(BM/2) + h*(BM/4) + [0, BM/4) for wm' = 0,1.
-    // W rows are PERMUTED on the way into LDS: LDS row (wn, nh, j', r') of the tile holds output
-    // column wn*64 + 16*(r'>>2) + 4*(2*nh + j') + (r'&3), so that the four column tiles of a lane
-    // (C/D layout: column 4*fg + reg of tile jj) are the 16 adjacent columns wn*64 + 16*fg + 4*jj + reg.
-    unsigned a_m[2][NA], w_n[2][NW];
-    int a_lds[2][NA], w_lds[2][NW];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    // ---- direct-to-LDS loaders ----------------------------------------------------------------
+    // A half h, instruction i: 8-row group g = w*NA + i; the half's rows are wm'*(BM/2) + h*(BM/4) + [0, BM/4).
+    // W rows are PERMUTED on the way into LDS: LDS row (wn, nh, j', r') holds output column
+    // wn*64 + 16*(r'>>2) + 4*(2*nh + j') + (r'&3), so that the four column tiles of a lane (C/D
+    // layout: column 4*fg + reg of tile jj) are the 16 adjacent columns wn*64 + 16*fg + 4*jj + reg.
+    // addresses = wave-uniform base + 32-bit per-lane byte offset (operands are < 4 GiB);
+    // nothing per-lane is kept between calls: row = uniform part + lr, 2 VALU per load.
+    // per-lane byte offsets (kernel-invariant): row part (lr or the permuted W row) * ld + chunk
+    const unsigned voA1 = ((unsigned)lr * (unsigned)p.lda1 + csw) * 2u, voA2 = ((unsigned)lr * (unsigned)p.lda2 + csw) * 2u;
+    const unsigned voW1 = (wl * (unsigned)p.ldw1 + csw) * 2u, voW2 = (wl * (unsigned)p.ldw2 + csw) * 2u;
+    auto issueA = [&](int bm, int h, int T) {
+        constexpr int NA = BM / 128, BUF = (BM + BN) * BK;
+        const bool ext = T >= nk1;
+        const char* Ap = (const char*)(ext ? p.A2 : p.A1);
+        const unsigned lda = ext ? p.lda2 : p.lda1, k0 = (ext ? T - nk1 : T) * BK, vo = ext ? voA2 : voA1;
+        bf16* dst = sm + (T & 1) * BUF;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int g = w * NA + i;
-            const int chunk = g / (BM / 32), gi = g % (BM / 32);
-            a_lds[h][i] = (chunk * (BM / 2) + h * (BM / 4) + gi * 8) * BK;
+            const int r0 = (g / (BM / 32)) * (BM / 2) + h * (BM / 4) + (g % (BM / 32)) * 8;
+            const unsigned so = ((unsigned)(bm * BM + r0) * lda + k0) * 2u;      // wave-uniform
+            glds16(Ap + (size_t)(vo + so), dst + r0 * BK);
         }
+    };
+    auto issueW = [&](int bn, int h, int T) {
+        constexpr int BUF = (BM + BN) * BK;
+        const bool ext = T >= nk1;
+        const char* Wp = (const char*)(ext ? p.W2 : p.W1);
+        const unsigned ldw = ext ? p.ldw2 : p.ldw1, k0 = (ext ? T - nk1 : T) * BK, vo = ext ? voW2 : voW1;
+        bf16* dst = sm + (T & 1) * BUF + BM * BK;
 #pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const int g = w * NW + i;
+        for (int i = 0; i < 2; ++i) {
+            const int g = w * 2 + i;
             const int chunk = g >> 2, gi = g & 3;
-            w_lds[h][i] = BM * BK + (chunk * 64 + h * 32 + gi * 8) * BK;
-        }
-    }
-    auto set_tile = [&](int bm, int bn) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                int m = bm * BM + a_lds[h][i] / BK + lr;
-                if (p.a_gather) m = m < p.Mvalid ? m + m / p.patches + 1 : 0;
-                a_m[h][i] = (unsigned)m;
-            }
-#pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                const int g = w * NW + i;
-                const int chunk = g >> 2, gi = g & 3;
-                const int jp = gi >> 1, rp = (gi & 1) * 8 + lr;          // j', r' of this lane's LDS row
-                w_n[h][i] = (unsigned)(bn * BN + chunk * 64 + 16 * (rp >> 2) + 4 * (2 * h + jp) + (rp & 3));
-            }
+            // LDS row (chunk, h, j' = gi>>1, r' = (gi&1)*8 + lr)  <-  column chunk*64 + 16*(r'>>2) + 4*(2h+j') + (r'&3)
+            const unsigned so = ((unsigned)(bn * BN + chunk * 64 + 4 * (2 * h + (gi >> 1)) + 32 * (gi & 1)) * ldw + k0) * 2u;
+            glds16(Wp + (size_t)(vo + so), dst + (chunk * 64 + h * 32 + gi * 8) * BK);
         }
     };
-    const unsigned csw = (unsigned)((lc ^ lr) * 8);   // swizzled source chunk (row & 7 == lr for every group)
-
-    // addresses = wave-uniform base + 32-bit per-lane byte offset (operands are < 4 GiB)
-    auto issueA = [&](int h, int T) {
-        const char* Ap; unsigned lda, k0;
-        if (T < nk1) { Ap = (const char*)p.A1; lda = p.lda1; k0 = T * BK; } else { Ap = (const char*)p.A2; lda = p.lda2; k0 = (T - nk1) * BK; }
-        bf16* dst = sm + (T & 1) * BUF;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) glds16(Ap + (size_t)((a_m[h][i] * lda + k0 + csw) * 2u), dst + a_lds[h][i]);
-    };
-    auto issueW = [&](int h, int T) {
-        const char* Wp; unsigned ldw, k0;
-        if (T < nk1) { Wp = (const char*)p.W1; ldw = p.ldw1; k0 = T * BK; } else { Wp = (const char*)p.W2; ldw = p.ldw2; k0 = (T - nk1) * BK; }
-        bf16* dst = sm + (T & 1) * BUF;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) glds16(Wp + (size_t)((w_n[h][i] * ldw + k0 + csw) * 2u), dst + w_lds[h][i]);
-    };
-    auto prologue = [&]() {     // K tile 0 complete, A0/W0 of K tile 1
-        issueA(0, 0); issueW(0, 0); issueW(1, 0); issueA(1, 0);
-        issueA(0, 1); issueW(0, 1);
+    auto prologue = [&](int bm, int bn) {     // K tile 0 complete, A0/W0 of K tile 1
+        issueA(bm, 0, 0); issueW(bn, 0, 0); issueW(bn, 1, 0); issueA(bm, 1, 0);
+        issueA(bm, 0, 1); issueW(bn, 0, 1);
     };
 
-    // ---- fragment addressing ------------------------------------------------------------------
-    const int xo0 = ((0 + fg) ^ (fr & 7)) * 8, xo1 = ((4 + fg) ^ (fr & 7)) * 8;   // k-step 0 / 1 chunk
-    const int a_base = (wm * (BM / 2) + fr) * BK;                // + mh*(BM/4)*BK + i*16*BK
-    const int w_base = BM * BK + (wn * 64 + fr) * BK;            // + nh*32*BK + j*16*BK
+    // A tile that is not the workgroup's first is entered with at least EX "older" VMEM
+    // instructions (the previous tile's epilogue) queued behind its first loads.  They may still
+    // be in flight when the tile starts: the waits of K tile 0 count them instead of draining
+    // them, so the stores of one tile retire under the MFMAs of the next.
+    constexpr int EX = (BM / 32) * epilogue_vmem_per_row<EPI>();   // BM/32 16-row blocks per lane
 
-    f32x4 acc[2 * MI][4];
-    bf16x8 af[2][MI], wf[2][2][2];
+    // One output tile: main loop over K (its first 6 half-tiles are already issued), then
+    // `issue_next()` (starts the next tile's loads), then the epilogue.
+    auto run_tile = [&](int bm, int bn, bool first, auto&& issue_next) {
+        constexpr int BUF = (BM + BN) * BK;
+        constexpr int MI = BM / 64;             // 16-row MFMA tiles per output quadrant (m)
+        constexpr int NA = BM / 128, NW = 2;
+        constexpr int STEADY = 2 * NA + 2 * NW;
+        const int xo0 = ((0 + fg) ^ (fr & 7)) * 8, xo1 = ((4 + fg) ^ (fr & 7)) * 8;   // k-step 0 / 1 chunk
+        const int a_base = (wm * (BM / 2) + fr) * BK;            // + mh*(BM/4)*BK + i*16*BK
+        const int w_base = BM * BK + (wn * 64 + fr) * BK;        // + nh*32*BK + j*16*BK
 
-    auto readA = [&](const bf16* buf, int mh) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const bf16* r = buf + a_base + (mh * (BM / 4) + i * 16) * BK;
-            af[0][i] = *(const bf16x8*)(r + xo0);
-            af[1][i] = *(const bf16x8*)(r + xo1);
-        }
-    };
-    auto readW = [&](const bf16* buf, int nh) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const bf16* r = buf + w_base + (nh * 32 + j * 16) * BK;
-            wf[nh][0][j] = *(const bf16x8*)(r + xo0);
-            wf[nh][1][j] = *(const bf16x8*)(r + xo1);
-        }
-    };
-    auto mma = [&](int mh, int nh) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[mh * MI + i][nh * 2 + j] = mfma16(wf[nh][ks][j], af[ks][i], acc[mh * MI + i][nh * 2 + j]);
-        __builtin_amdgcn_s_setprio(0);
-    };
-
-    // MODE 0: steady state (K tiles T+1 and T+2 exist); 1: T = nk-2; 2: T = nk-1
-    auto ktile = [&](int T, auto mode) {
-        constexpr int MODE = decltype(mode)::value;
-        const bf16* buf = sm + (T & 1) * BUF;
-        // P1
-        readA(buf, 0);
-        readW(buf, 0);
-        if constexpr (MODE <= 1) { issueW(1, T + 1); VMCNT(STEADY); } else { VMCNT(NA); }
-        BARRIER();
-        mma(0, 0);
-        // P2
-        readW(buf, 1);
-        if constexpr (MODE <= 1) { issueA(1, T + 1); VMCNT(STEADY); } else { VMCNT(0); }
-        BARRIER();
-        mma(0, 1);
-        // P3
-        readA(buf, 1);
-        if constexpr (MODE == 0) issueA(0, T + 2);
-        BARRIER();
-        mma(1, 1);
-        // P4
-        if constexpr (MODE == 0) { issueW(0, T + 2); VMCNT(STEADY); }
-        if constexpr (MODE == 1) { VMCNT(NA + NW); }
-        BARRIER();
-        mma(1, 0);
-    };
-
-    int cur = tile_of(0);
-    if (cur < 0) return;
-    int bm = cur / tilesN, bn = cur - bm * tilesN;
-    set_tile(bm, bn);
-    prologue();
-
-    for (int it = 0;; ++it) {
+        f32x4 acc[2 * MI][4];
+        bf16x8 af[2][MI], wf[2][2][2];
 #pragma unroll
         for (int i = 0; i < 2 * MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // everything issued so far (prologue loads, previous epilogue's stores) retired by every wave
-        VMCNT(0);
+
+        auto readA = [&](const bf16* buf, int mh) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const bf16* r = buf + a_base + (mh * (BM / 4) + i * 16) * BK;
+                af[0][i] = *(const bf16x8*)(r + xo0);
+                af[1][i] = *(const bf16x8*)(r + xo1);
+            }
+        };
+        auto readW = [&](const bf16* buf, int nh) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16* r = buf + w_base + (nh * 32 + j * 16) * BK;
+                wf[nh][0][j] = *(const bf16x8*)(r + xo0);
+                wf[nh][1][j] = *(const bf16x8*)(r + xo1);
+            }
+        };
+        auto mma = [&](int mh, int nh) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[mh * MI + i][nh * 2 + j] = mfma16(wf[nh][ks][j], af[ks][i], acc[mh * MI + i][nh * 2 + j]);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        // MODE 0: steady state (K tiles T+1 and T+2 exist); 1: T = nk-2; 2: T = nk-1
+        // EXC: older in-flight epilogue instructions to tolerate (K tile 0 only)
+        auto ktile = [&](int T, auto mode, auto extra) {
+            constexpr int MODE = decltype(mode)::value;
+            constexpr int EXC = decltype(extra)::value;
+            const bf16* buf = sm + (T & 1) * BUF;
+            // P1
+            readA(buf, 0);
+            readW(buf, 0);
+            if constexpr (MODE <= 1) { issueW(bn, 1, T + 1); VMCNT(clamp63(STEADY + EXC)); } else { VMCNT(NA); }
+            BARRIER();
+            mma(0, 0);
+            BARRIER();
+            // P2
+            readW(buf, 1);
+            if constexpr (MODE <= 1) { issueA(bm, 1, T + 1); VMCNT(clamp63(STEADY + EXC)); } else { VMCNT(0); }
+            BARRIER();
+            mma(0, 1);
+            BARRIER();
+            // P3
+            readA(buf, 1);
+            if constexpr (MODE == 0) issueA(bm, 0, T + 2);
+            BARRIER();
+            mma(1, 1);
+            BARRIER();
+            // P4
+            if constexpr (MODE == 0) { issueW(bn, 0, T + 2); VMCNT(clamp63(STEADY + EXC)); }
+            if constexpr (MODE == 1) { VMCNT(clamp63(NA + NW + EXC)); }
+            BARRIER();
+            mma(1, 0);
+            BARRIER();
+        };
+
+        // this tile's first loads (A0, W0 of K tile 0) retired by every wave; the EX younger
+        // epilogue instructions of the previous tile and the 4 later half-tiles may stay in flight
+        // (a workgroup's first tile has no older epilogue in flight: drain, which also satisfies
+        //  every wait of K tile 0, all of them on loads issued before this point)
+        if (first) VMCNT(0);
+        VMCNT(clamp63(STEADY + EX));
         BARRIER();
-
-        for (int T = 0; T + 2 < nk; ++T) ktile(T, std::integral_constant<int, 0>{});
-        ktile(nk - 2, std::integral_constant<int, 1>{});
-        ktile(nk - 1, std::integral_constant<int, 2>{});
-
-        // next output tile: its first loads go out before this tile's epilogue
-        const int nxt = tile_of(it + 1);
-        const int cbm = bm, cbn = bn;
-        // (every wave passed the last phase's barrier only after its final ds_reads completed,
-        //  so LDS may be refilled from here on without another barrier)
-        if (nxt >= 0) {
-            bm = nxt / tilesN; bn = nxt - bm * tilesN;
-            set_tile(bm, bn);
-            prologue();
+        if (wm == 1) BARRIER();                      // stagger: waves 4-7 trail by one barrier
+        if (nk > 2) {
+            ktile(0, IC<0>{}, IC<EX>{});
+            for (int T = 1; T + 2 < nk; ++T) ktile(T, IC<0>{}, IC<0>{});
+            ktile(nk - 2, IC<1>{}, IC<0>{});
+        } else {
+            ktile(0, IC<1>{}, IC<EX>{});
         }
+        ktile(nk - 1, IC<2>{}, IC<0>{});
+        if (wm == 0) BARRIER();                      // waves 0-3 rejoin (equal barrier counts)
+        // every wave passed the last barrier only after its final ds_reads completed: LDS may be refilled
+        issue_next();
 
-        // ---- epilogue of tile (cbm, cbn) ----------------------------------------------------
         f32x4 bv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int n0 = cbn * BN + wn * 64 + fg * 16;      // this lane's 16 adjacent columns
+        const int n0 = bn * BN + wn * 64 + fg * 16;  // this lane's 16 adjacent columns
         if (p.bias) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(p.bias + n0 + 4 * j);
         }
 #pragma unroll
         for (int i = 0; i < 2 * MI; ++i) {
-            const int m = cbm * BM + wm * (BM / 2) + i * 16 + fr;
+            const int m = bm * BM + wm * (BM / 2) + i * 16 + fr;
             f32x4 v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = acc[i][j] + bv[j];
             epilogue_row16<EPI>(p, m, n0, v);
         }
-        if (nxt < 0) break;
+    };
+
+    // Workgroups that share an XCD (blockIdx % 8 under round-robin placement; a speed assumption
+    // only) take 1/8 of each round's tiles as a contiguous run, so neighbouring tiles (same A row
+    // panel, all of W) meet in one L2.
+    auto tile_of = [&](int it) -> int {
+        const int base = it * G;
+        const int cnt = min(G, ntiles - base);
+        if (bid >= cnt) return -1;
+        return base + xcd_remap(bid, cnt);
+    };
+    int cur = tile_of(0);
+    if (cur < 0) return;
+    prologue(bm0 + cur / tilesN, cur % tilesN);
+    for (int it = 0; cur >= 0; ++it) {
+        const int nxt = tile_of(it + 1);
+        run_tile(bm0 + cur / tilesN, cur % tilesN, it == 0, [&]() {
+            if (nxt >= 0) prologue(bm0 + nxt / tilesN, nxt % tilesN);
+        });
+        cur = nxt;
     }
 }
 
 int g_num_cus = 0;
 
-template <int BM, int EPI>
-void launch_t(const GemmArgs& a, hipStream_t s) {
-    const int ntiles = (a.M / BM) * (a.N / BN);
-    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16);
-    const int grid = ntiles < g_num_cus ? ntiles : g_num_cus;
-    hipLaunchKernelGGL((gemm256_kernel<BM, EPI>), dim3(grid), dim3(512), lds, s, a);
+// Choose how many 256-row tile rows stay "big"; the rest of the rows become 128-row tiles that
+// must fit one round (<= G workgroups).  cost = big rounds + 0.55 per small round.
+bool plan_tiles(int M, int N, int G, int* nbig, int* nsmall) {
+    const int tilesN = N / BN, rows256 = M / 256, rows128 = M / 128;
+    double best = 1e30;
+    bool ok = false;
+    for (int give = 0; give <= rows256; ++give) {
+        const int big_rows = rows256 - give;
+        const long nb = (long)big_rows * tilesN, ns = (long)(rows128 - 2 * big_rows) * tilesN;
+        if (ns > G) break;
+        const double cost = (double)((nb + G - 1) / G) + (ns > 0 ? 0.55 : 0.0);
+        if (cost < best - 1e-9) { best = cost; *nbig = (int)nb; *nsmall = (int)ns; ok = true; }
+    }
+    return ok;
 }
 
 template <int BM, int EPI>
-void set_attr() {
-    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16);
-    (void)hipFuncSetAttribute((const void*)gemm256_kernel<BM, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+void launch_one(const GemmArgs& a, int ntiles, int bm0, hipStream_t s) {
+    if (ntiles <= 0) return;
+    const int grid = ntiles < g_num_cus ? ntiles : g_num_cus;
+    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16) + 1024;
+    hipLaunchKernelGGL((gemm256_kernel<BM, EPI>), dim3(grid), dim3(512), lds, s, a, ntiles, bm0);
 }
 
 template <int EPI>
-void launch_bm(const GemmArgs& a, hipStream_t s) {
-    // 256-row tiles unless the last, partly filled round of workgroups costs more than the
-    // (slightly less efficient) 128-row tiles would: rounds are over the CUs.
-    const long c = g_num_cus;
-    const long t256 = (long)(a.M / 256) * (a.N / BN), t128 = (long)(a.M / 128) * (a.N / BN);
-    const double r256 = (double)((t256 + c - 1) / c), r128 = 0.5 * (double)((t128 + c - 1) / c);
-    const bool use256 = (a.M % 256 == 0) && r256 <= 1.08 * r128;
-    if (use256) launch_t<256, EPI>(a, s); else launch_t<128, EPI>(a, s);
+void launch_t(const GemmArgs& a, hipStream_t s) {
+    int nbig = 0, nsmall = 0;
+    plan_tiles(a.M, a.N, g_num_cus, &nbig, &nsmall);
+    launch_one<256, EPI>(a, nbig, 0, s);
+    launch_one<128, EPI>(a, nsmall, (nbig / (a.N / BN)) * 2, s);
 }
+
+template <int BM, int EPI>
+void set_attr1() {
+    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16) + 1024;
+    (void)hipFuncSetAttribute((const void*)gemm256_kernel<BM, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+template <int EPI>
+void set_attr() { set_attr1<256, EPI>(); set_attr1<128, EPI>(); }
 
 }  // namespace
 
 bool gemm256_supports(const GemmArgs& a, int epi) {
+    if (a.a_gather) return false;          // the patch-gradient GEMM (row-gathered A) stays on the 128-row kernel
     if (a.N % BN || a.M % 128 || a.K1 % BK || a.K2 % BK) return false;
     if ((a.K1 + a.K2) / BK < 2) return false;
+    int nb, ns;
     (void)epi;
-    return true;
+    return plan_tiles(a.M, a.N, g_num_cus ? g_num_cus : 256, &nb, &ns);
 }
 
 void gemm256_init() {
@@ -289,23 +334,19 @@ void gemm256_init() {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
         g_num_cus = prop.multiProcessorCount;
     if (g_num_cus <= 0) g_num_cus = 256;
-    set_attr<256, EPI_STORE_BF16>(); set_attr<128, EPI_STORE_BF16>();
-    set_attr<256, EPI_RESID_F32>(); set_attr<128, EPI_RESID_F32>();
-    set_attr<256, EPI_GELU>(); set_attr<128, EPI_GELU>();
-    set_attr<256, EPI_GELU_BWD>(); set_attr<128, EPI_GELU_BWD>();
-    set_attr<256, EPI_PATCH_FWD>(); set_attr<128, EPI_PATCH_FWD>();
-    set_attr<256, EPI_PATCH_BWD>(); set_attr<128, EPI_PATCH_BWD>();
-    set_attr<256, EPI_STORE_F32>(); set_attr<128, EPI_STORE_F32>();
+    set_attr<EPI_STORE_BF16>(); set_attr<EPI_RESID_F32>(); set_attr<EPI_GELU>(); set_attr<EPI_GELU_BWD>();
+    set_attr<EPI_PATCH_FWD>(); set_attr<EPI_PATCH_BWD>(); set_attr<EPI_STORE_F32>(); set_attr<EPI_NONE>();
 }
 
 void launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
     switch (epi) {
-        case EPI_STORE_BF16: launch_bm<EPI_STORE_BF16>(a, s); break;
-        case EPI_RESID_F32: launch_bm<EPI_RESID_F32>(a, s); break;
-        case EPI_GELU: launch_bm<EPI_GELU>(a, s); break;
-        case EPI_GELU_BWD: launch_bm<EPI_GELU_BWD>(a, s); break;
-        case EPI_PATCH_FWD: launch_bm<EPI_PATCH_FWD>(a, s); break;
-        case EPI_PATCH_BWD: launch_bm<EPI_PATCH_BWD>(a, s); break;
-        case EPI_STORE_F32: launch_bm<EPI_STORE_F32>(a, s); break;
+        case EPI_STORE_BF16: launch_t<EPI_STORE_BF16>(a, s); break;
+        case EPI_RESID_F32: launch_t<EPI_RESID_F32>(a, s); break;
+        case EPI_GELU: launch_t<EPI_GELU>(a, s); break;
+        case EPI_GELU_BWD: launch_t<EPI_GELU_BWD>(a, s); break;
+        case EPI_PATCH_FWD: launch_t<EPI_PATCH_FWD>(a, s); break;
+        case EPI_PATCH_BWD: launch_t<EPI_PATCH_BWD>(a, s); break;
+        case EPI_STORE_F32: launch_t<EPI_STORE_F32>(a, s); break;
+        case EPI_NONE: launch_t<EPI_NONE>(a, s); break;
     }
 }

@@ -120,6 +120,9 @@ __device__ __forceinline__ void epilogue_row16(const GemmArgs& p, int m, int n0,
         bf16* dst = (bf16*)p.C + (size_t)m * p.ldc + n0;
         *(bf16x8*)dst = pack8(o[0], o[1]);
         *(bf16x8*)(dst + 8) = pack8(o[2], o[3]);
+    } else if constexpr (EPI == EPI_NONE) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("" ::"v"(v[q]));
     } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) epilogue_store<EPI>(p, m, n0 + 4 * q, v[q]);

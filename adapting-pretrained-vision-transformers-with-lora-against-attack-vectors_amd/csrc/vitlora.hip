@@ -726,6 +726,7 @@ int vl_bench_gemm(int M, int N, int K1, int K2, int epi, int bn, int iters, floa
     GemmArgs g = gemm_args(A, K1, W, K1, K1, M, N);
     if (K2) add_ext(g, A2, K2, W2, K2, K2);
     g.bias = bias; g.C = C; g.ldc = N; g.C2 = C2; g.ldc2 = N; g.R = R; g.ldr = N;
+    if (epi >= 100) { epi -= 100; g.ldc = 0; g.ldc2 = 0; }     // diagnostic: every row stored to row 0 (no HBM write stream)
     if (epi == EPI_RESID_F32) g.R = C;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));

@@ -17,11 +17,13 @@ ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 else None     # e.g. "qkv fwd
 ITERS = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 M = B * 197
 M = (M + 255) // 256 * 256
-EPI = {0: "store_bf16", 1: "resid_f32", 2: "gelu", 3: "gelu_bwd", 6: "store_f32"}
+EPI = {0: "store_bf16", 1: "resid_f32", 2: "gelu", 3: "gelu_bwd", 6: "store_f32", 7: "none", 100: "bf16->row0", 102: "gelu->row0"}
 shapes = [  # (name, N, K1, K2, epi)
     ("qkv fwd", 2304, 768, 64, 0), ("o fwd", 768, 768, 64, 1), ("fc1 fwd", 3072, 768, 0, 2),
     ("fc2 fwd", 768, 3072, 64, 1), ("fc2 dgrad", 3072, 768, 64, 3), ("fc1 dgrad", 768, 3072, 0, 0),
     ("o dgrad", 768, 768, 64, 0), ("qkv dgrad", 768, 2304, 64, 0),
+    ("nostore 3072x768", 3072, 768, 0, 7), ("nostore 768x3072", 768, 3072, 0, 7), ("nostore 2304x768", 2304, 768, 0, 7),
+    ("row0 3072x768", 3072, 768, 0, 100), ("row0gelu 3072x768", 3072, 768, 0, 102),
     ("plain 3072x768", 3072, 768, 0, 0), ("plain 768x3072", 768, 3072, 0, 0), ("square 4096^3", 4096, 4096, 0, 0),
 ]
 tot_ms = tot_fl = 0.0
@@ -36,7 +38,7 @@ for name, N, K1, K2, epi in shapes:
         continue
     fl = 2.0 * m * N * (K1 + K2)
     print(f"{name:16s} M={m} N={N:5d} K={K1}+{K2:2d} {EPI[epi]:10s} {ms.value * 1e3:8.1f} us  {fl / ms.value / 1e9:7.1f} TFLOP/s")
-    if not name.startswith(("plain", "square")):
+    if not name.startswith(("plain", "square", "nostore", "row0")):
         tot_ms += ms.value
         tot_fl += fl
 print(f"layer total (8 GEMMs): {tot_ms * 1e3:.1f} us, {tot_fl / tot_ms / 1e9:.1f} TFLOP/s (padded-K flops)")
