@@ -1,0 +1,365 @@
+// Attention forward / backward, second generation: 32x32x16 bf16 MFMA (half the LDS bytes per
+// FLOP of the 16x16x32 version), K/V/Q/dO images filled by direct-to-LDS loads, 32-query /
+// 32-key work items.  Same math and same interfaces as attention.hip (HF eager attention,
+// modeling_vit.py:164-189, and its backward); T <= 224 tokens, head_dim 64.
+//
+// LDS image of one [rows][64] bf16 operand: rows of 128 B, 16-byte chunk c of row r stored at
+// chunk c ^ f(r), f(r) = ((r>>1)&1)<<2 | ((r>>2)&3).  With that f both access kinds used here
+// are bank-conflict free:
+//   * row fragments  (ds_read_b128, lane = row of a 32-row tile, all lanes of a half-wave the
+//     same chunk): operands whose MFMA k index is the head dimension d;
+//   * transposed fragments (ds_read_b64_tr_b16, 4 rows x 16 columns per 16-lane group):
+//     operands whose k index is the token index.
+// Score tiles are computed with the token index that is NOT summed next on the LANE (queries
+// for S^T = K Q^T, keys for S = Q K^T): the accumulator is then directly the B operand of the
+// following product (k order inside a 16-deep step: 8*(j>>2) + 4*(lane>>5) + (j&3), applied
+// to both operands), and softmax statistics / LSE / delta are per-lane scalars.
+#include "kernels.h"
+#include "prof.h"
+
+namespace {
+
+constexpr int HD = 64;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+
+// row fragment of a 32-row tile: lane (r = lane&31, h = lane>>5) gets img[row0 + r][16*ks + 8*h .. +7]
+__device__ __forceinline__ bf16x8 row_frag32(const bf16* img, int row, int ks, int h) {
+    return *(const bf16x8*)(img + row * HD + (((2 * ks + h) ^ swz(row)) << 3));
+}
+// transposed fragment: element j of lane (c = lane&31, h = lane>>5) = img[t0 + 8*(j>>2) + 4*h + (j&3)][c0 + c]
+// (t0 multiple of 16, c0 multiple of 32).  16-lane group g = lane>>4: columns c0 + 16*(g&1) + [0,16), h = g>>1;
+// lane i = 4q + p of the group supplies the address of row q, columns 4p..4p+3 of the 4 x 16 block.
+__device__ __forceinline__ bf16x8 tr_frag32(const bf16* img, int t0, int c0, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int h = g >> 1, q = i >> 2, p = i & 3;
+    const int col = c0 + 16 * (g & 1) + 4 * p;
+    const int r0 = t0 + 4 * h + q, r1 = r0 + 8;
+    const bf16* a0 = img + r0 * HD + (((col >> 3) ^ swz(r0)) << 3) + (col & 4);
+    const bf16* a1 = img + r1 * HD + (((col >> 3) ^ swz(r1)) << 3) + (col & 4);
+    return cat4(lds_read_tr16(a0), lds_read_tr16(a1));
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {   // registers 8s .. 8s+7
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(v[8 * s + j]);
+    return o;
+}
+// fill rows [0, ROWS) of a swizzled image from global rows min(r, T-1) (row stride ld elements):
+// one 1 KiB direct-to-LDS load per 8 rows, groups dealt round-robin to NW waves.
+template <int ROWS, int NW>
+__device__ __forceinline__ void stage_glds(bf16* img, const bf16* src, int ld, int T, int w, int lane) {
+    const int lr = lane >> 3, lc = lane & 7;
+    for (int g = w; g < ROWS / 8; g += NW) {
+        const int r = g * 8 + lr;
+        const int rs = r < T ? r : T - 1;
+        glds16(src + (size_t)rs * ld + ((lc ^ swz(r)) << 3), img + g * 8 * HD);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward: one workgroup (8 waves) per (image, head); each wave owns 32-query blocks.
+// NT = number of 32-key tiles (ROWS = 32*NT >= T).
+// ------------------------------------------------------------------------------------------
+constexpr int FWD_WAVES = 8;
+template <int NT>
+__global__ __launch_bounds__(64 * FWD_WAVES) void attn_fwd32_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ ctx,
+                                                            float* __restrict__ lse2, int T, int H, int D, float scale_log2e) {
+    constexpr int ROWS = NT * 32;
+    __shared__ __attribute__((aligned(16))) bf16 sm[2 * ROWS * HD];
+    bf16* sK = sm;
+    bf16* sV = sm + ROWS * HD;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x / H, hd = blockIdx.x - b * H;
+    const int ld = 3 * D;
+    const bf16* base = qkv + (size_t)b * T * ld + hd * HD;
+    stage_glds<ROWS, FWD_WAVES>(sK, base + D, ld, T, w, lane);
+    stage_glds<ROWS, FWD_WAVES>(sV, base + 2 * D, ld, T, w, lane);
+
+    const int nqb = (T + 31) >> 5;
+    int qb = w;
+    bf16x8 qf[4];
+    auto load_q = [&](int blk) {
+        const int q = blk * 32 + c;
+        const bf16* qr = base + (size_t)(q < T ? q : T - 1) * ld + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qr + 16 * ks);
+    };
+    if (qb < nqb) load_q(qb);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int nkt = (T + 31) >> 5;                  // key tiles that hold at least one valid key
+    const int tcut = T - 4 * h;                     // key < T  <=>  kt*32 + (r&3) + 8*(r>>2) < tcut
+    for (; qb < nqb; qb += FWD_WAVES) {
+        // online softmax over 32-key tiles (running max m, running sum l per query = per lane pair)
+        float m = -INFINITY, l = 0.f;
+        f32x16 o[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll 1
+        for (int kt = 0; kt < nkt; ++kt) {
+            // S^T tile: rows = keys, column = query c
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s = mfma32(row_frag32(sK, kt * 32 + c, ks, h), qf[ks], s);
+            // m, tmax are in RAW score units (the softmax scale is positive); p = exp2(s*c - m*c)
+            float tmax = -INFINITY;
+            if (kt * 32 + 32 > T) {                 // partial tile (wave-uniform): mask keys >= T
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((kt * 32 + (r & 3) + 8 * (r >> 2)) >= tcut) s[r] = -INFINITY;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            if (__any(tmax > m)) {                  // some row's running max grew: rescale (first tile: always)
+                const float mn = fmaxf(m, tmax);    // finite: key 0 of tile 0 is always valid
+                const float alpha = exp2f((m - mn) * scale_log2e);   // first tile: exp2(-inf) = 0, l = 0, o = 0
+                m = mn;
+                l *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            }
+            const float mc = -m * scale_log2e;
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = exp2f(fmaf(s[r], scale_log2e, mc)); ps += s[r]; }
+            l += ps;
+            // O^T += V^T P^T: rows = d, column = query c
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const bf16x8 pb = pack8(s, st);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(tr_frag32(sV, kt * 32 + 16 * st, dt * 32, lane), pb, o[dt]);
+            }
+        }
+        l += __shfl_xor(l, 32, 64);
+        const int q = qb * 32 + c;
+        const float inv = 1.f / l;
+        if (q < T) {
+            bf16* dst = ctx + ((size_t)b * T + q) * D + hd * HD + 4 * h;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    bf16x4 ov;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ov[k] = f2bf(o[dt][4 * rq + k] * inv);
+                    *(bf16x4*)(dst + dt * 32 + 8 * rq) = ov;
+                }
+            if (h == 0) lse2[((size_t)b * H + hd) * T + q] = m * scale_log2e + log2f(l);
+        }
+        if (qb + FWD_WAVES < nqb) load_q(qb + FWD_WAVES);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward: one workgroup (8 waves) per (image, head).  Work items: NB key blocks (phase B:
+// dK, dV; key on the lane) and NB query blocks (phase A: dQ; query on the lane), 32 tokens each.
+// ------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ ctx,
+                                                         const bf16* __restrict__ dctx, const float* __restrict__ lse2,
+                                                         bf16* __restrict__ dqkv, int T, int H, int D, float scale,
+                                                         float scale_log2e) {
+    constexpr int ROWS = NT * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* sQ = (bf16*)smem;
+    bf16* sK = sQ + ROWS * HD;
+    bf16* sV = sK + ROWS * HD;
+    bf16* sdO = sV + ROWS * HD;
+    float* sLse = (float*)(sdO + ROWS * HD);
+    float* sDelta = sLse + ROWS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x / H, hd = blockIdx.x - b * H;
+    const int ld = 3 * D;
+    const bf16* base = qkv + (size_t)b * T * ld + hd * HD;
+    const bf16* dobase = dctx + (size_t)b * T * D + hd * HD;
+    const bf16* obase = ctx + (size_t)b * T * D + hd * HD;
+    stage_glds<ROWS, 8>(sQ, base, ld, T, w, lane);
+    stage_glds<ROWS, 8>(sK, base + D, ld, T, w, lane);
+    stage_glds<ROWS, 8>(sV, base + 2 * D, ld, T, w, lane);
+    stage_glds<ROWS, 8>(sdO, dobase, D, T, w, lane);
+    // delta[r] = sum_d dO[r][d] * O[r][d]; LSE (rows >= T: +inf so that P = 0 there)
+    for (int idx = tid; idx < ROWS * 8; idx += 512) {
+        const int r = idx >> 3, cc = idx & 7;
+        float part = 0.f;
+        if (r < T) {
+            const bf16x8 dv = *(const bf16x8*)(dobase + (size_t)r * D + cc * 8);
+            const bf16x8 ov = *(const bf16x8*)(obase + (size_t)r * D + cc * 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) part += bf2f(dv[k]) * bf2f(ov[k]);
+        }
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64);
+        if (cc == 0) {
+            sDelta[r] = part;
+            sLse[r] = r < T ? lse2[((size_t)b * H + hd) * T + r] : INFINITY;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int nb = (T + 31) >> 5;
+    for (int item = w; item < 2 * nb; item += 8) {
+        if (item < nb) {
+            // ---------------- phase B: key block on the lane ----------------
+            const int key = item * 32 + c;
+            bf16x8 kf[4], vf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { kf[ks] = row_frag32(sK, key, ks, h); vf[ks] = row_frag32(sV, key, ks, h); }
+            f32x16 dv[2], dk[2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { dv[dt][r] = 0.f; dk[dt][r] = 0.f; }
+#pragma unroll 1
+            for (int qt = 0; qt < NT; ++qt) {
+                f32x16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    s = mfma32(row_frag32(sQ, qt * 32 + c, ks, h), kf[ks], s);       // S[q][key]
+                    dp = mfma32(row_frag32(sdO, qt * 32 + c, ks, h), vf[ks], dp);    // dP[q][key]
+                }
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const f32x4 lq = *(const f32x4*)(sLse + qt * 32 + 8 * rq + 4 * h);
+                    const f32x4 dl = *(const f32x4*)(sDelta + qt * 32 + 8 * rq + 4 * h);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float p = exp2f(fmaf(s[4 * rq + k], scale_log2e, -lq[k]));   // rows >= T: 0
+                        s[4 * rq + k] = p;
+                        dp[4 * rq + k] = p * (dp[4 * rq + k] - dl[k]);     // dS / scale (folded into dK below)
+                    }
+                }
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const bf16x8 pb = pack8(s, st), dsb = pack8(dp, st);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        dv[dt] = mfma32(tr_frag32(sdO, qt * 32 + 16 * st, dt * 32, lane), pb, dv[dt]);   // dV^T[d][key]
+                        dk[dt] = mfma32(tr_frag32(sQ, qt * 32 + 16 * st, dt * 32, lane), dsb, dk[dt]);   // dK^T[d][key]
+                    }
+                }
+            }
+            if (key < T) {
+                bf16* dst = dqkv + ((size_t)b * T + key) * ld + hd * HD + 4 * h;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        bf16x4 kv, vv;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { kv[k] = f2bf(dk[dt][4 * rq + k] * scale); vv[k] = f2bf(dv[dt][4 * rq + k]); }
+                        *(bf16x4*)(dst + D + dt * 32 + 8 * rq) = kv;
+                        *(bf16x4*)(dst + 2 * D + dt * 32 + 8 * rq) = vv;
+                    }
+            }
+        } else {
+            // ---------------- phase A: query block on the lane ----------------
+            const int q = (item - nb) * 32 + c;
+            bf16x8 qf[4], dof[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { qf[ks] = row_frag32(sQ, q, ks, h); dof[ks] = row_frag32(sdO, q, ks, h); }
+            const float lse_q = sLse[q], delta_q = sDelta[q];
+            f32x16 dq[2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+#pragma unroll 1
+            for (int kt = 0; kt < NT; ++kt) {
+                f32x16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    s = mfma32(row_frag32(sK, kt * 32 + c, ks, h), qf[ks], s);        // S^T[key][q]
+                    dp = mfma32(row_frag32(sV, kt * 32 + c, ks, h), dof[ks], dp);     // dP^T[key][q]
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float p = key < T ? exp2f(fmaf(s[r], scale_log2e, -lse_q)) : 0.f;
+                    dp[r] = p * (dp[r] - delta_q);                          // dS / scale (folded into dQ below)
+                }
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const bf16x8 dsb = pack8(dp, st);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(tr_frag32(sK, kt * 32 + 16 * st, dt * 32, lane), dsb, dq[dt]);
+                }
+            }
+            if (q < T) {
+                bf16* dst = dqkv + ((size_t)b * T + q) * ld + hd * HD + 4 * h;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        bf16x4 ov;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) ov[k] = f2bf(dq[dt][4 * rq + k] * scale);
+                        *(bf16x4*)(dst + dt * 32 + 8 * rq) = ov;
+                    }
+            }
+        }
+    }
+}
+
+template <int NT>
+size_t bwd_lds() { return (size_t)4 * NT * 32 * HD * sizeof(bf16) + (size_t)2 * NT * 32 * sizeof(float); }
+
+template <int NT>
+void launch_bwd(const bf16* qkv, const bf16* ctx, const bf16* dctx, const float* lse2, bf16* dqkv, int B, int T, int H,
+                int D, hipStream_t s) {
+    const float scale = 0.125f;   // 64^-1/2
+    hipLaunchKernelGGL((attn_bwd32_kernel<NT>), dim3(B * H), dim3(512), bwd_lds<NT>(), s, qkv, ctx, dctx, lse2, dqkv, T,
+                       H, D, scale, scale * 1.4426950408889634f);
+}
+
+}  // namespace
+
+void attention32_init() {
+    static bool done = false;
+    if (done) return;
+    (void)hipFuncSetAttribute((const void*)attn_bwd32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<1>());
+    (void)hipFuncSetAttribute((const void*)attn_bwd32_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<7>());
+    done = true;
+}
+
+int k_attention32_fwd(const bf16* qkv, bf16* ctx, float* lse2, int B, int T, int H, int D, hipStream_t s) {
+    ProfScope prof_("attn_fwd32_kernel", 4.0 * B * H * (double)T * T * HD, (double)B * T * D * 8.0, s);
+    const float sl = 0.125f * 1.4426950408889634f;
+    if (T <= 32) hipLaunchKernelGGL((attn_fwd32_kernel<1>), dim3(B * H), dim3(64 * FWD_WAVES), 0, s, qkv, ctx, lse2, T, H, D, sl);
+    else if (T <= 224) hipLaunchKernelGGL((attn_fwd32_kernel<7>), dim3(B * H), dim3(64 * FWD_WAVES), 0, s, qkv, ctx, lse2, T, H, D, sl);
+    else return -1;
+    return 0;
+}
+
+int k_attention32_bwd(const bf16* qkv, const bf16* ctx, const bf16* dctx, const float* lse2, bf16* dqkv, int B, int T,
+                      int H, int D, hipStream_t s) {
+    ProfScope prof_("attn_bwd32_kernel", 10.0 * B * H * (double)T * T * HD, (double)B * T * D * 16.0, s);
+    if (T <= 32) launch_bwd<1>(qkv, ctx, dctx, lse2, dqkv, B, T, H, D, s);
+    else if (T <= 224) launch_bwd<7>(qkv, ctx, dctx, lse2, dqkv, B, T, H, D, s);
+    else return -1;
+    return 0;
+}

@@ -8,8 +8,8 @@
 enum GemmEpilogue {
     EPI_STORE_BF16 = 0,   // C(bf16) = acc + bias
     EPI_RESID_F32 = 1,    // C(f32)  = acc + bias + R(f32)        (R may alias C)
-    EPI_GELU = 2,         // C2(bf16) = z = acc + bias ; C(bf16) = gelu(z)
-    EPI_GELU_BWD = 3,     // C(bf16) = acc * gelu'(R(bf16))
+    EPI_GELU = 2,         // z = acc + bias ; C(bf16) = gelu(z) ; C2(bf16) = gelu'(z)
+    EPI_GELU_BWD = 3,     // C(bf16) = acc * R(bf16), R = the saved gelu'(z)
     EPI_PATCH_FWD = 4,    // C(f32)[row b*T + 1 + p] = acc + bias + pos[1+p]
     EPI_PATCH_BWD = 5,    // image-layout scatter of d(patches), scaled by 1/std[c]
     EPI_STORE_F32 = 6,    // C(f32) = acc + bias
@@ -34,6 +34,7 @@ struct GemmArgs {
     int a_gather;
     // algorithmic sizes for profiling (0 = use N / K2): true LoRA rank columns, not the padded ones
     int n_algo, k2_algo;
+    int dephase;      // gemm256: start offset unit (x 8128 cycles x (workgroup/8 mod 4)); 0 = off
 };
 
 // bn = 128 (default) or 64 (skinny LoRA-down GEMMs)

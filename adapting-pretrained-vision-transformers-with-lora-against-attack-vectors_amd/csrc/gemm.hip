@@ -9,6 +9,7 @@
 // conflict-free ds_read_b128 fragment reads), one barrier per K step, 16x16x32 MFMA with the
 // operands swapped so that each lane owns 4 consecutive output columns (8/16-byte stores).
 #include <cstdio>
+#include <cstdlib>
 
 #include "gemm_epi.h"
 #include "prof.h"
@@ -144,6 +145,7 @@ void set_attr() {
 }
 
 int g_force_small = -1;
+int g_dephase = -1;
 
 }  // namespace
 
@@ -161,6 +163,8 @@ void gemm_init() {
     gemm256_init();
     const char* e = getenv("VITLORA_GEMM128");      // A/B switch: force the 128-row kernel
     g_force_small = (e && e[0] == '1') ? 1 : 0;
+    const char* dp = getenv("VITLORA_DEPHASE");      // experiment knob: start-offset unit of gemm256
+    if (dp) g_dephase = atoi(dp);
     done = true;
 }
 
@@ -171,7 +175,9 @@ void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
     if (bn != 64 && g_force_small != 1 && gemm256_supports(a, epi)) {
         snprintf(name, sizeof name, "gemm256_kernel<%d>", epi);
         ProfScope prof_(name, flops, 0.0, s);
-        launch_gemm256(a, epi, s);
+        GemmArgs b = a;
+        if (g_dephase >= 0) b.dephase = g_dephase;
+        launch_gemm256(b, epi, s);
         return;
     }
     snprintf(name, sizeof name, "gemm_nt_kernel<%d, %d>", bn == 64 ? 64 : 128, epi);

@@ -265,6 +265,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
     };
     int cur = tile_of(0);
     if (cur < 0) return;
+    // De-phase the workgroups: without this every CU computes, then every CU stores its tile at
+    // the same moment (HBM idle, then a 32 MB write burst).  Quarter-tile start offsets spread
+    // the epilogue traffic of neighbouring CUs over the whole round.
+    if (p.dephase > 0) {
+        for (int i = (bid >> 3) & 3; i > 0; --i)
+            for (int j = 0; j < p.dephase; ++j) __builtin_amdgcn_s_sleep(127);
+    }
     prologue(bm0 + cur / tilesN, cur % tilesN);
     for (int it = 0; cur >= 0; ++it) {
         const int nxt = tile_of(it + 1);

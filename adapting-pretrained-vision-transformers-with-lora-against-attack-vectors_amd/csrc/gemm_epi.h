@@ -35,15 +35,20 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
         const f32x4 r = *(const f32x4*)((const float*)p.R + (size_t)m * p.ldr + n);
         *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v + r;
     } else if constexpr (EPI == EPI_GELU) {
-        bf16x4 z = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        bf16x4 a = {f2bf(gelu_fast(v[0])), f2bf(gelu_fast(v[1])), f2bf(gelu_fast(v[2])), f2bf(gelu_fast(v[3]))};
-        *(bf16x4*)((bf16*)p.C2 + (size_t)m * p.ldc2 + n) = z;
+        bf16x4 g, a;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const GeluParts gp = gelu_parts(v[i]);
+            a[i] = f2bf(v[i] * gp.cdf);
+            g[i] = f2bf(fmaf(v[i], gp.pdf, gp.cdf));
+        }
+        *(bf16x4*)((bf16*)p.C2 + (size_t)m * p.ldc2 + n) = g;
         *(bf16x4*)((bf16*)p.C + (size_t)m * p.ldc + n) = a;
     } else if constexpr (EPI == EPI_GELU_BWD) {
         const bf16x4 z = *(const bf16x4*)((const bf16*)p.R + (size_t)m * p.ldr + n);
         bf16x4 o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = f2bf(v[i] * gelu_grad_fast(bf2f(z[i])));
+        for (int i = 0; i < 4; ++i) o[i] = f2bf(v[i] * bf2f(z[i]));
         *(bf16x4*)((bf16*)p.C + (size_t)m * p.ldc + n) = o;
     } else if constexpr (EPI == EPI_PATCH_FWD) {
         if (m < p.Mvalid) {
@@ -95,27 +100,35 @@ __device__ __forceinline__ void epilogue_row16(const GemmArgs& p, int m, int n0,
 #pragma unroll
         for (int q = 0; q < 4; ++q) *(f32x4*)(dst + 4 * q) = v[q] + rv[q];
     } else if constexpr (EPI == EPI_GELU) {
-        f32x4 a[4];
+        // C = gelu(z); C2 = gelu'(z) = Phi(z) + z phi(z): the backward needs only this derivative,
+        // and exp(-z^2/2) is already at hand here, so it costs two more FMAs instead of a second
+        // erf + exp pass in the dgrad epilogue.
+        f32x4 a[4], g[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a[q][k] = gelu_fast(v[q][k]);
-        bf16* zd = (bf16*)p.C2 + (size_t)m * p.ldc2 + n0;
+            for (int k = 0; k < 4; ++k) {
+                const GeluParts gp = gelu_parts(v[q][k]);
+                a[q][k] = v[q][k] * gp.cdf;
+                g[q][k] = fmaf(v[q][k], gp.pdf, gp.cdf);
+            }
+        bf16* gd = (bf16*)p.C2 + (size_t)m * p.ldc2 + n0;
         bf16* ad = (bf16*)p.C + (size_t)m * p.ldc + n0;
-        *(bf16x8*)zd = pack8(v[0], v[1]);
-        *(bf16x8*)(zd + 8) = pack8(v[2], v[3]);
+        *(bf16x8*)gd = pack8(g[0], g[1]);
+        *(bf16x8*)(gd + 8) = pack8(g[2], g[3]);
         *(bf16x8*)ad = pack8(a[0], a[1]);
         *(bf16x8*)(ad + 8) = pack8(a[2], a[3]);
     } else if constexpr (EPI == EPI_GELU_BWD) {
+        // R = gelu'(z) saved by the forward epilogue
         const bf16* zs = (const bf16*)p.R + (size_t)m * p.ldr + n0;
         const bf16x8 z0 = *(const bf16x8*)zs, z1 = *(const bf16x8*)(zs + 8);
         f32x4 o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            o[0][k] = v[0][k] * gelu_grad_fast(bf2f(z0[k]));
-            o[1][k] = v[1][k] * gelu_grad_fast(bf2f(z0[4 + k]));
-            o[2][k] = v[2][k] * gelu_grad_fast(bf2f(z1[k]));
-            o[3][k] = v[3][k] * gelu_grad_fast(bf2f(z1[4 + k]));
+            o[0][k] = v[0][k] * bf2f(z0[k]);
+            o[1][k] = v[1][k] * bf2f(z0[4 + k]);
+            o[2][k] = v[2][k] * bf2f(z1[k]);
+            o[3][k] = v[3][k] * bf2f(z1[4 + k]);
         }
         bf16* dst = (bf16*)p.C + (size_t)m * p.ldc + n0;
         *(bf16x8*)dst = pack8(o[0], o[1]);

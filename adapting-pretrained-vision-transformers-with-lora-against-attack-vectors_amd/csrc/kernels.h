@@ -37,6 +37,12 @@ int k_attention_fwd(const bf16* qkv, bf16* ctx, float* lse2, int B, int T, int H
 int k_attention_bwd(const bf16* qkv, const bf16* ctx, const bf16* dctx, const float* lse2, bf16* dqkv, int B, int T,
                     int H, int D, hipStream_t s);
 
+// attention32.hip (32x32x16 MFMA generation; same interfaces)
+void attention32_init();
+int k_attention32_fwd(const bf16* qkv, bf16* ctx, float* lse2, int B, int T, int H, int D, hipStream_t s);
+int k_attention32_bwd(const bf16* qkv, const bf16* ctx, const bf16* dctx, const float* lse2, bf16* dqkv, int B, int T,
+                      int H, int D, hipStream_t s);
+
 // lora_grad.hip
 // dB[n][j] (+)= sum_m dy[m][n] * t[m][j] ; dA[j][k] (+)= sum_m u[m][j] * x[m][k]  (fp32 outputs)
 void k_lora_wgrad(const bf16* L, int ldl, int ncols_l, const bf16* Rm, int ldr, int ncols_r, int M, float scale,

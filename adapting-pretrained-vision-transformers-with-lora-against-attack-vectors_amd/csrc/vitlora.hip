@@ -107,6 +107,7 @@ struct vl_model {
     hipStream_t cap_stream = nullptr;
     struct { const void* x0; const void* labels; void* adv; int B; float eps, alpha; } gkey = {};
     int use_graph = 1;
+    int attn16 = 0;       // VITLORA_ATTN16=1: first-generation (16x16x32) attention kernels, for A/B runs
     int plan_batch = 0, plan_train = 0;
     float mean[3] = {0.485f, 0.456f, 0.406f};   // get_normalization, Utils.py:92-93
     float stdv[3] = {0.229f, 0.224f, 0.225f};
@@ -203,6 +204,7 @@ int vl_create(const vl_config* cfg, vl_model** out) {
 
     gemm_init();
     attention_init();
+    attention32_init();
     vl_model* m = new vl_model();
     m->cfg = *cfg;
     m->D = cfg->hidden; m->L = cfg->layers; m->H = cfg->heads; m->MLP = cfg->mlp;
@@ -212,6 +214,8 @@ int vl_create(const vl_config* cfg, vl_model** out) {
     m->scaling = m->r ? cfg->lora_alpha / (float)m->r : 0.f;
     const char* ng = getenv("VITLORA_NO_GRAPH");
     m->use_graph = !(ng && ng[0] == '1');
+    const char* a16 = getenv("VITLORA_ATTN16");
+    m->attn16 = (a16 && a16[0] == '1') ? 1 : 0;
     const int D = m->D, MLP = m->MLP, r = m->r;
     int rc;
 #define A_(p, n) if ((rc = dev_alloc(m, &(p), (size_t)(n))) != VL_OK) { vl_destroy(m); return rc; }
@@ -484,7 +488,7 @@ static int forward_impl(vl_model* m, const float* x, int B, int normalise, int t
         k_layernorm_fwd(w.xs[2 * l], w.h1[l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, ly.ln1_b, M, D, m->cfg.ln_eps, s);
         memset(&g, 0, sizeof g); g.C = w.qkv[l]; g.ldc = 3 * D;
         linear_fwd(m, ly.lin[LQKV], w.h1[l], w.t[LQKV][l], Mpad, g, EPI_STORE_BF16, s);
-        if (k_attention_fwd(w.qkv[l], w.ctx[l], w.lse[l], B, T, m->H, D, s)) return fail(VL_ERR_UNSUPPORTED, "attention: T > 224");
+        if ((m->attn16 ? k_attention_fwd : k_attention32_fwd)(w.qkv[l], w.ctx[l], w.lse[l], B, T, m->H, D, s)) return fail(VL_ERR_UNSUPPORTED, "attention: T > 224");
         memset(&g, 0, sizeof g); g.C = w.xs[2 * l + 1]; g.ldc = D; g.R = w.xs[2 * l]; g.ldr = D;
         linear_fwd(m, ly.lin[LO], w.ctx[l], w.t[LO][l], Mpad, g, EPI_RESID_F32, s);
         k_layernorm_fwd(w.xs[2 * l + 1], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D,
@@ -570,7 +574,7 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
         memset(&g, 0, sizeof g); g.C = w.dctx; g.ldc = D;
         linear_dgrad(m, ly.lin[LO], w.dres_bf, w.u, Mpad, g, EPI_STORE_BF16, s);
         wgrad(ly.lin[LO], w.dres_bf, w.ctx[l], w.t[LO][l], w.u);
-        if (k_attention_bwd(w.qkv[l], w.ctx[l], w.dctx, w.lse[l], w.dqkv, B, T, m->H, D, s))
+        if ((m->attn16 ? k_attention_bwd : k_attention32_bwd)(w.qkv[l], w.ctx[l], w.dctx, w.lse[l], w.dqkv, B, T, m->H, D, s))
             return fail(VL_ERR_UNSUPPORTED, "attention: T > 224");
         memset(&g, 0, sizeof g); g.C = w.dh; g.ldc = D;
         linear_dgrad(m, ly.lin[LQKV], w.dqkv, w.u, Mpad, g, EPI_STORE_BF16, s);
