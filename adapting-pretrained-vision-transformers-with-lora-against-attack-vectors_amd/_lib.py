@@ -35,6 +35,7 @@ SIGNATURES = {
     "vl_param_tensor": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "vl_param_flat": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "vl_lora_commit": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vl_merge_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vl_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "vl_set_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "vl_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

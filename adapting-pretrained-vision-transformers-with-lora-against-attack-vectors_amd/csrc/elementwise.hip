@@ -402,8 +402,24 @@ __global__ void merge_lora_kernel(const float* __restrict__ W, const float* __re
     dst[(int64_t)(roff + o) * ldd + k] = v;
     dstT[(int64_t)k * lddT + coffT + o] = v;
 }
+// fp32 form of the same fold (adapter composition: the merged weight becomes the next base)
+__global__ void merge_f32_kernel(const float* __restrict__ W, const float* __restrict__ A, const float* __restrict__ Bm,
+                                 int out, int in, int r, float s, float* __restrict__ dst) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)out * in) return;
+    const int o = (int)(i / in), k = (int)(i - (int64_t)o * in);
+    float a = 0.f;
+    for (int j = 0; j < r; ++j) a += Bm[(int64_t)o * r + j] * A[(int64_t)j * in + k];
+    dst[i] = W[i] + s * a;
+}
 
 }  // namespace
+
+void k_merge_f32(const float* W, const float* A, const float* B, int out, int in, int r, float sc, float* dst,
+                 hipStream_t s) {
+    const int64_t n = (int64_t)out * in;
+    hipLaunchKernelGGL(merge_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, A, B, out, in, r, sc, dst);
+}
 
 // ---------------------------------------------------------------------------------
 // host launchers

@@ -31,6 +31,9 @@ void k_pack_bf16_t(const float* src, bf16* dst, int rows, int cols, int ldd, int
 void k_merge_lora(const float* W, const float* A, const float* B, int out, int in, int r, float sc, bf16* dst, int ldd,
                   int roff, bf16* dstT, int lddT, int coffT, hipStream_t s);
 
+void k_merge_f32(const float* W, const float* A, const float* B, int out, int in, int r, float sc, float* dst,
+                 hipStream_t s);
+
 // attention.hip
 void attention_init();   // one-time kernel attributes (outside any stream capture)
 int k_attention_fwd(const bf16* qkv, bf16* ctx, float* lse2, int B, int T, int H, int D, hipStream_t s);

@@ -389,6 +389,21 @@ int vl_lora_commit(vl_model* m, void* stream) {
     return VL_OK;
 }
 
+// merge_and_unload for one module (eval_compose.py:110): W_out = W_in + (alpha/r) * B A in fp32 on
+// the device.  W_in / W_out: [out, in] fp32 device buffers of the caller (may alias).
+int vl_merge_weight(vl_model* m, int layer, uint32_t target, const float* W_in, float* W_out, void* stream) {
+    if (!m || !W_in || !W_out) return fail(VL_ERR_ARG, "null argument");
+    if (layer < 0 || layer >= m->L) return fail(VL_ERR_ARG, "layer out of range");
+    for (int k = 0; k < 4; ++k)
+        for (const Slot& sl : m->layers[layer].lin[k].slots)
+            if (kTargetBits[sl.target_idx] == target) {
+                k_merge_f32(W_in, m->flat + sl.a_off, m->flat + sl.b_off, sl.out, sl.in, m->r, m->scaling, W_out,
+                            (hipStream_t)stream);
+                return VL_OK;
+            }
+    return fail(VL_ERR_ARG, "target 0x%x has no adapter in layer %d", target, layer);
+}
+
 // ---- workspace -------------------------------------------------------------------------------
 static size_t carve(vl_model* m, int B, int train, char* base) {
     Workspace& w = m->ws;

@@ -174,6 +174,10 @@ class Engine:
         check(self.lib.vl_lora_commit(self.h, self._stream()), "vl_lora_commit")
 
     def set_normalization(self, mean, std):
+        key = (tuple(float(v) for v in mean), tuple(float(v) for v in std))
+        if getattr(self, "_norm_key", None) == key:
+            return                               # unchanged: keep the cached PGD graph
+        self._norm_key = key
         m = (C.c_float * 3)(*[float(v) for v in mean])
         s = (C.c_float * 3)(*[float(v) for v in std])
         check(self.lib.vl_set_normalization(self.h, m, s), "vl_set_normalization")

@@ -87,6 +87,10 @@ int vl_param_flat(vl_model* m, float** ptr, int64_t* numel);
  * merge_and_unload (train_loras.py:419, eval_compose.py:108-110). */
 int vl_lora_commit(vl_model* m, void* stream);
 
+/* merge_and_unload for one adapted module (eval_compose.py:102-114): W_out = W_in + (alpha/r) B A,
+ * fp32 [out,in] device buffers of the caller (may alias); A, B are the module's current adapters. */
+int vl_merge_weight(vl_model* m, int layer, uint32_t target, const float* W_in, float* W_out, void* stream);
+
 /* mean/std used when normalise != 0 (default: ImageNet constants of get_normalization,
  * Utils.py:92-93; torchattacks' set_normalization_used(mean, std), whitebox_attacks.py:169). */
 int vl_set_normalization(vl_model* m, const float mean[3], const float std[3]);

@@ -1,0 +1,185 @@
+"""GPU tests of the drop-in surface: the reference's model / attack / peft callables on the HIP
+engine, checked against the oracle and against the golden vectors made by the reference's own
+`batched_fgsm_attack` + HF ViT (tests/golden/)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import O, PKG, make_case, pkg, rel_l2
+from test_oracle_golden import load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(cfg, w, num_labels=None):
+    P = pkg()
+    arch = P.ArchConfig(image_size=cfg.image_size, patch_size=cfg.patch_size, hidden=cfg.hidden, layers=cfg.layers,
+                        heads=cfg.heads, mlp=cfg.mlp, num_labels=cfg.num_labels, ln_eps=cfg.ln_eps)
+    m = P.create_vit_model(cfg.num_labels, arch=arch)
+    m.load_state_dict(w)
+    return m.eval()
+
+
+@pytest.mark.parametrize("name", ["tiny17", "tiny197", "vitb"])
+def test_golden_reference_fgsm_and_logits(name):
+    """HIP path vs what the REFERENCE produced (HF ViT logits, input gradient, FGSM decisions)."""
+    P = pkg()
+    cfg, w, x, y, z = load_case(name)
+    model = _model(cfg, w)
+    mean, std = P.get_normalization("google_vit")
+    mt, st = torch.tensor(mean).view(1, 3, 1, 1), torch.tensor(std).view(1, 3, 1, 1)
+    logits = P.LogitsModel(model)(((x - mt) / st).cuda()).cpu()
+    assert rel_l2(logits, torch.from_numpy(z["logits"])) < 1e-2          # north_star bf16 tolerance
+    adv = P.batched_fgsm_attack(model, x.cuda(), y.cuda(), float(z["eps"]), mt.cuda(), st.cuda()).cpu()
+    assert abs((adv - x).abs().max().item() - float(z["adv_absmax"])) < 1e-6
+    ref_sign = torch.from_numpy(z["adv_minus_x_sign"])
+    g_ref = torch.from_numpy(z["grad"])
+    sign = torch.sign(adv - x).to(torch.int8)
+    # decisions may differ only where the reference gradient is inside the bf16 noise floor
+    big = (g_ref.abs() > 0.1 * g_ref.abs().mean()) & (ref_sign != 0)
+    agree_big = (sign[big] == ref_sign[big]).float().mean().item()
+    agree_all = (sign == ref_sign).float().mean().item()
+    assert agree_big > 0.97 and agree_all > 0.90, (agree_big, agree_all)
+
+
+def test_reference_style_autograd_fgsm():
+    """The reference's FGSM body (whitebox_attacks.py:24-36) written with torch ops against OUR model
+    object: requires_grad_ -> normalise -> model -> F.cross_entropy -> backward -> .grad."""
+    P = pkg()
+    cfg, w, lora, x, y = make_case(batch=3, r=0)
+    model = _model(cfg, w)
+    mean, std = P.get_normalization(None)
+    mt, st = torch.tensor(mean).view(1, 3, 1, 1).cuda(), torch.tensor(std).view(1, 3, 1, 1).cuda()
+    perturbed = x.cuda().clone().detach().requires_grad_(True)
+    outputs = model((perturbed - mt) / st)
+    loss = F.cross_entropy(P.get_model_output(outputs), y.cuda())
+    loss.backward()
+    l_ref, g_ref, _ = O.loss_and_input_grad(w, cfg, x, y)
+    assert abs(loss.item() - l_ref.item()) < 1e-2 * abs(l_ref.item())
+    assert rel_l2(perturbed.grad.cpu(), g_ref) < 2e-2
+
+
+def test_pgd_class_canonical_and_torchattacks_compat():
+    P = pkg()
+    cfg, w, lora, x, y = make_case(batch=4, r=0)
+    model = _model(cfg, w)
+    eps, alpha, steps = 8 / 255, 2 / 255, 4
+    mean, std = P.get_normalization(None)
+    # compat: the reference's call pattern (set_normalization_used on [0,1] images)
+    atk = P.PGD(P.LogitsModel(model), eps=eps, alpha=alpha, steps=steps, random_start=False)
+    atk.set_normalization_used(mean=mean, std=std)
+    adv = atk(x.cuda(), y.cuda()).cpu()
+    ref = O.pgd_torchattacks_compat(w, cfg, x, y, eps, alpha, steps)
+    st = torch.tensor(std).view(1, 3, 1, 1)
+    d, dr = (adv - x) * st, (ref - x) * st            # perturbation in the attack's own space
+    assert d.abs().max().item() <= eps + 1e-5
+    agree = (torch.sign(d) == torch.sign(dr)).float().mean().item()
+    assert agree > 0.9, agree
+    # no normalisation registered: model consumes the adversarial image directly
+    atk2 = P.PGD(P.LogitsModel(model), eps=eps, alpha=alpha, steps=steps, random_start=False)
+    adv2 = atk2(x.cuda(), y.cuda()).cpu()
+    adv_o = x.clone()
+    for _ in range(steps):
+        _, g, _ = O.loss_and_input_grad(w, cfg, adv_o, y, normalised=True)
+        adv_o = O.pgd_step(adv_o, x, g, eps, alpha)
+    assert (torch.sign(adv2 - x) == torch.sign(adv_o - x)).float().mean().item() > 0.9
+    # FGSM class == batched_fgsm_attack when the same normalisation is registered
+    f = P.FGSM(P.LogitsModel(model), eps=eps)
+    a1 = f(O.normalise(x).cuda(), y.cuda()).cpu()      # no set_normalization_used: model fed as is
+    a_ref = torch.clamp(O.normalise(x) + eps * torch.sign(O.loss_and_input_grad(w, cfg, O.normalise(x), y, normalised=True)[1]), 0, 1)
+    assert (torch.sign(a1 - O.normalise(x)) == torch.sign(a_ref - O.normalise(x))).float().mean().item() > 0.9
+
+
+def test_peft_roundtrip_and_merge(tmp_path):
+    P = pkg()
+    cfg, w, lora, x, y = make_case(batch=3)
+    base = _model(cfg, w)
+    pm = P.setup_peft_lora(base, rank=lora.r, alpha=lora.alpha, dropout=0.0)
+    eng = pm._vit._engine()
+    # peft init: B = 0 -> the adapted model equals the base model
+    xn = O.normalise(x).cuda()
+    pm.eval()
+    l0 = pm.base_model(pixel_values=xn).logits.detach().cpu()
+    assert rel_l2(l0, base(xn).logits.detach().cpu()) < 2e-3
+    for (i, t), (A, B) in lora.ab.items():
+        eng.param(i, t, "A").copy_(A)
+        eng.param(i, t, "B").copy_(B)
+    pm._vit.mark_dirty()
+    l1 = pm.base_model(pixel_values=xn).logits.detach().cpu()
+    assert rel_l2(l1, O.vit_forward(w, cfg, O.normalise(x), lora)) < 1e-2
+    d = str(tmp_path / "adapter")
+    pm.save_pretrained(d)
+    assert sorted(os.listdir(d)) == ["adapter_config.json", "adapter_model.safetensors"]
+    from safetensors.torch import load_file
+    sd = load_file(os.path.join(d, "adapter_model.safetensors"))
+    assert "base_model.model.vit.encoder.layer.0.attention.attention.query.lora_A.weight" in sd
+    assert "base_model.model.vit.encoder.layer.1.output.dense.lora_B.weight" in sd
+    assert "base_model.model.classifier.weight" in sd
+    assert len(sd) == cfg.layers * 5 * 2 + 2
+    pm2 = P.PeftModel.from_pretrained(_model(cfg, w), d)
+    l2 = pm2.base_model(pixel_values=xn).logits.detach().cpu()
+    assert torch.allclose(l1, l2, rtol=0, atol=1e-5)
+    merged = pm2.merge_and_unload()
+    l3 = merged(xn).logits.detach().cpu()
+    assert rel_l2(l3, l1) < 1e-2
+
+
+def test_lora_training_steps_match_oracle():
+    """train_loras.py:303-315 with the same objects: base_model(pixel_values=...).logits,
+    CrossEntropyLoss, backward, Adam.step -- three steps, compared with torch autograd + oracle Adam."""
+    P = pkg()
+    cfg, w, lora, x, y = make_case(batch=4)
+    base = _model(cfg, w)
+    pm = P.setup_peft_lora(base, rank=lora.r, alpha=lora.alpha, dropout=0.0)
+    eng = pm._vit._engine()
+    for (i, t), (A, B) in lora.ab.items():
+        eng.param(i, t, "A").copy_(A)
+        eng.param(i, t, "B").copy_(B)
+    pm._vit.mark_dirty()
+    pm.train()
+    crit = torch.nn.CrossEntropyLoss()
+    lr = 1e-3
+    opt = P.Adam(pm.parameters(), lr=lr, model=pm)
+    xn = O.normalise(x)
+    # oracle state
+    ol = O.OracleLora(r=lora.r, alpha=lora.alpha, targets=lora.targets, ab={k: (a.clone(), b.clone()) for k, (a, b) in lora.ab.items()})
+    ow = dict(w)
+    mom = {}
+    losses_hip, losses_ref = [], []
+    for step in range(1, 4):
+        opt.zero_grad()
+        logits = pm.base_model(pixel_values=xn.cuda()).logits
+        loss = crit(logits, y.cuda())
+        loss.backward()
+        opt.step()
+        losses_hip.append(loss.item())
+        l_ref, _, grads = O.lora_train_grads(ow, cfg, xn, y, ol)
+        losses_ref.append(l_ref.item())
+        for key, g in grads.items():
+            if key[0] == "cls":
+                name = "classifier." + key[1]
+                p = ow[name]
+            else:
+                A, B = ol.ab[key[1:]]
+                p = A if key[0] == "A" else B
+            m_, v_ = mom.get(key, (torch.zeros_like(p), torch.zeros_like(p)))
+            p2, m_, v_ = O.adam_step(p, g, m_, v_, step, lr=lr)
+            mom[key] = (m_, v_)
+            if key[0] == "cls":
+                ow[name] = p2
+            else:
+                A, B = ol.ab[key[1:]]
+                ol.ab[key[1:]] = (p2, B) if key[0] == "A" else (A, p2)
+    assert all(abs(a - b) < 2e-2 * abs(b) for a, b in zip(losses_hip, losses_ref)), (losses_hip, losses_ref)
+    assert losses_hip[-1] < losses_hip[0]
+    # parameters after 3 Adam steps (Adam normalises the step: compare the direction of the update)
+    for (i, t) in list(lora.ab.keys())[:6]:
+        for which, idx in (("A", 0), ("B", 1)):
+            got = eng.param(i, t, which).cpu() - lora.ab[(i, t)][idx]
+            want = ol.ab[(i, t)][idx] - lora.ab[(i, t)][idx]
+            cos = float((got * want).sum() / (got.norm() * want.norm() + 1e-30))
+            assert cos > 0.9, (i, t, which, cos)

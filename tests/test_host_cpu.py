@@ -1,0 +1,135 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol of include/vitlora.h, the
+host-side logic (peft target matching, key renaming, parameter counts, sharding) and the
+data-parallel exchange step on the gloo backend with world_size 2."""
+import importlib
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from helpers import O, PKG, ROOT, pkg
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "vitlora.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vl_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_header_symbol():
+    lib_mod = importlib.import_module(PKG + "._lib")
+    names = header_functions()
+    assert len(names) >= 25 and "vl_pgd_attack" in names and "vl_backward_lora" in names
+    missing_sig = [n for n in names if n not in lib_mod.SIGNATURES]
+    assert not missing_sig, f"ctypes binding lacks {missing_sig}"
+    lib = lib_mod.load()            # raises if the .so is missing: there is no CPU fallback
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.vl_version().decode().startswith("vitlora-hip")
+    assert set(lib_mod.SIGNATURES) - set(names) <= {"vl_bench_gemm"}   # binding has nothing the header lacks
+
+
+def test_engine_refuses_to_run_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    P = pkg()
+    with pytest.raises(P.VitLoraError):
+        P.Engine(P.ArchConfig())
+
+
+def test_target_resolution_and_key_renaming():
+    P = pkg()
+    assert P.resolve_targets(["query", "key", "value", "output.dense"]) == ("q", "k", "v", "o", "fc2")
+    assert P.resolve_targets(["query", "value"]) == ("q", "v")
+    assert P.resolve_targets(["intermediate.dense"]) == ("fc1",)
+    assert P.resolve_targets([]) == ()
+    assert P.canonical_key("vit.layers.3.attention.q_proj.weight") == "vit.encoder.layer.3.attention.attention.query.weight"
+    assert P.canonical_key("vit.layers.0.attention.o_proj.bias") == "vit.encoder.layer.0.attention.output.dense.bias"
+    assert P.canonical_key("vit.layers.11.mlp.fc2.weight") == "vit.encoder.layer.11.output.dense.weight"
+    assert P.canonical_key("classifier.weight") == "classifier.weight"
+    keys = P.expected_keys(P.ArchConfig())
+    assert len(keys) == 8 + 12 * 16 and set(keys) == set(O.init_weights(O.OracleConfig()).keys())
+
+
+def test_peft_parameter_count_known_answers():
+    """infLora.ipynb:163, :919 -- r=4 / r=16 on query,value with the 101-class head saved."""
+    pc = importlib.import_module(PKG + ".peft_compat")
+    model_mod = importlib.import_module(PKG + ".model")
+    P = pkg()
+
+    class _Stub(pc.PeftModel):
+        def __init__(self, arch, cfg):
+            torch.nn.Module.__init__(self)
+            self.config = cfg
+            self._vit = type("V", (), {"arch": arch})()
+
+    arch = P.ArchConfig(num_labels=101)
+    c4 = pc.LoraConfig(r=4, lora_alpha=16, target_modules=["query", "value"], modules_to_save=["classifier"])
+    assert _Stub(arch, c4).trainable_parameter_counts() == (225_125, 86_101_450)
+    c16 = pc.LoraConfig(r=16, lora_alpha=16, target_modules=["query", "value"], modules_to_save=["classifier"])
+    assert _Stub(arch, c16).trainable_parameter_counts() == (667_493, 86_543_818)
+    c8 = pc.LoraConfig(task_type=pc.TaskType.SEQ_CLS, r=8, target_modules=["query", "key", "value", "output.dense"])
+    tr, _ = _Stub(P.ArchConfig(num_labels=21), c8).trainable_parameter_counts()
+    assert tr == 958_464 + 768 * 21 + 21
+    assert model_mod.get_normalization("anything") == ([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+
+
+def test_shard_batch_partitions():
+    opt = importlib.import_module(PKG + ".optim")
+    for n, w in [(256, 8), (512, 8), (10, 3), (7, 8)]:
+        spans = [opt.shard_batch(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_synthetic_weights_match_oracle_init():
+    """bench.py's GPU weights (package synthetic.py) and its CPU baseline (oracle init) must be the same numbers."""
+    syn = importlib.import_module(PKG + ".synthetic")
+    P = pkg()
+    arch = P.ArchConfig(image_size=64, hidden=128, layers=2, heads=2, mlp=256, num_labels=10)
+    cfg = O.OracleConfig(image_size=64, hidden=128, layers=2, heads=2, mlp=256, num_labels=10)
+    a, b = syn.random_state_dict(arch, seed=3), O.init_weights(cfg, seed=3)
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+    la, lb = syn.random_lora(arch, 8, ("q", "k", "v", "o", "fc2"), seed=4), O.init_lora(cfg, r=8, seed=4).ab
+    assert la.keys() == lb.keys() and all(torch.equal(la[k][0], lb[k][0]) and torch.equal(la[k][1], lb[k][1]) for k in la)
+
+
+_WORKER = r'''
+import os, sys, torch, importlib
+import torch.distributed as dist
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+from helpers import O, PKG, make_case
+opt = importlib.import_module(PKG + ".optim")
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+rank = dist.get_rank()
+cfg, w, lora, x, y = make_case(batch=6, layers=1)
+xn = O.normalise(x)
+lo, hi = opt.shard_batch(6, rank, 2)
+_, _, g = O.lora_train_grads(w, cfg, xn[lo:hi], y[lo:hi], lora)          # mean over the LOCAL shard
+keys = sorted(g.keys(), key=str)
+flat = torch.cat([g[k].flatten() for k in keys])
+opt.allreduce_mean_(flat)                                                  # the ONE exchange step
+_, _, gf = O.lora_train_grads(w, cfg, xn, y, lora)                         # single-process full batch
+full = torch.cat([gf[k].flatten() for k in keys])
+err = float((flat - full).norm() / full.norm())
+print("rank", rank, "rel err", err, flush=True)
+assert err < 1e-5, err
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_gradient_exchange_gloo(tmp_path):
+    """Sum of shard gradients (mean-reduced) == single-process gradient: the N > 1 train step's only
+    collective, run on CPU tensors with gloo, world_size 2."""
+    port = 29500 + (os.getpid() % 2000)
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
