@@ -51,6 +51,9 @@ SIGNATURES = {
     "vl_pgd_attack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]),
     "vl_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int64, C.c_void_p]),
     "vl_quantize_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vl_set_dropout_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "vl_dropout_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vl_bench_gemm": (C.c_int, [C.c_int] * 7 + [C.POINTER(C.c_float)]),
     "vl_profile_begin": (C.c_int, []),
     "vl_profile_report": (C.c_int, [C.c_char_p, C.c_size_t]),
     "vl_debug_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),

@@ -56,6 +56,22 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
+// counter-based generator: splitmix64 finaliser on (seed, index)
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// LoRA dropout (lora_dropout of LoraConfig, train_loras.py:88): element `idx` of the branch input of
+// module `stream` is kept with probability 1-p; the mask is a pure function of (seed, stream, idx),
+// so forward, dgrad and wgrad regenerate it instead of storing it.  Returns 0 or 1/(1-p).
+__device__ __forceinline__ float drop_scale(uint64_t seed, uint32_t stream, uint64_t idx, float p, float inv_keep) {
+    const uint64_t r = mix64((seed * 0xD1342543DE82EF95ull) ^ ((uint64_t)stream << 48) ^ idx);
+    const float u = (float)(r >> 40) * (1.0f / 16777216.0f);
+    return u >= p ? inv_keep : 0.f;
+}
+
 // XCD-aware bijective remap of a linear workgroup id: workgroups that share an XCD
 // (id % 8 under round-robin placement) get a contiguous range of tiles -> neighbouring
 // tiles (same A row panel) hit the same L2.  Placement is a speed assumption only.

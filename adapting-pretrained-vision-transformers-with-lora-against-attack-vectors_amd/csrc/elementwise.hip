@@ -297,12 +297,7 @@ __global__ __launch_bounds__(256) void pgd_step_kernel(float* __restrict__ adv, 
 
 // K11: counter-based uniform noise (splitmix64 finaliser on (seed, index)); not torch's stream
 // (random_start=True, whitebox_attacks.py:113, needs a seeded deterministic start, not that stream).
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
+// (mix64 lives in common.h: the LoRA dropout mask uses the same generator)
 __global__ void pgd_init_kernel(float* __restrict__ adv, const float* __restrict__ x0, float eps, float lo, float hi,
                                 uint64_t seed, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -526,4 +521,37 @@ void k_merge_lora(const float* W, const float* A, const float* B, int out, int i
                   int roff, bf16* dstT, int lddT, int coffT, hipStream_t s) {
     hipLaunchKernelGGL(merge_lora_kernel, dim3(nblk((int64_t)out * in, 256)), dim3(256), 0, s, W, A, B, out, in, r, sc,
                        dst, ldd, roff, dstT, lddT, coffT);
+}
+
+// ---------------------------------------------------------------------------------
+// LoRA dropout (train mode): xd = x * mask/(1-p), mask = drop_scale(seed, stream, m*cols + c)
+// ---------------------------------------------------------------------------------
+namespace {
+__global__ void dropout_kernel(const bf16* __restrict__ x, bf16* __restrict__ xd, int64_t n8, uint64_t seed,
+                               uint32_t stream, float p, float inv_keep) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += stride) {
+        const bf16x8 v = *(const bf16x8*)(x + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = f2bf(bf2f(v[k]) * drop_scale(seed, stream, (uint64_t)(i * 8 + k), p, inv_keep));
+        *(bf16x8*)(xd + i * 8) = o;
+    }
+}
+__global__ void dropout_mask_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint32_t stream, float p,
+                                    float inv_keep) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = drop_scale(seed, stream, (uint64_t)i, p, inv_keep);
+}
+}  // namespace
+
+void k_dropout(const bf16* x, bf16* xd, int64_t n, uint64_t seed, uint32_t stream, float p, hipStream_t s) {
+    ProfScope prof_("dropout_kernel", 0.0, (double)n * 4.0, s);
+    hipLaunchKernelGGL(dropout_kernel, dim3(nblk(n / 8, 256, 4096)), dim3(256), 0, s, x, xd, n / 8, seed, stream, p,
+                       1.f / (1.f - p));
+}
+void k_dropout_mask(float* out, int64_t n, uint64_t seed, uint32_t stream, float p, hipStream_t s) {
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(nblk(n, 256, 4096)), dim3(256), 0, s, out, n, seed, stream, p,
+                       1.f / (1.f - p));
 }

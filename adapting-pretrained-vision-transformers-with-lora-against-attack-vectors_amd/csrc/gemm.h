@@ -14,6 +14,7 @@ enum GemmEpilogue {
     EPI_PATCH_BWD = 5,    // image-layout scatter of d(patches), scaled by 1/std[c]
     EPI_STORE_F32 = 6,    // C(f32) = acc + bias
     EPI_NONE = 7,         // diagnostic: results kept live, nothing stored (timing of the main loop alone)
+    EPI_DROP_ACC = 8,     // train-mode LoRA dgrad with dropout: C(bf16) = (R(bf16) + mask*acc) [* G(bf16)]
 };
 
 struct GemmArgs {
@@ -35,6 +36,9 @@ struct GemmArgs {
     // algorithmic sizes for profiling (0 = use N / K2): true LoRA rank columns, not the padded ones
     int n_algo, k2_algo;
     int dephase;      // gemm256: start offset unit (x 8128 cycles x (workgroup/8 mod 4)); 0 = off
+    // EPI_DROP_ACC: dropout mask of element (m, n) of the module input = drop_scale(seed, stream, m*N + n)
+    const bf16* G; int ldg;          // optional extra factor (gelu'(z) for the fc2 input gradient)
+    uint64_t drop_seed; uint32_t drop_stream; float drop_p, drop_inv_keep;
 };
 
 // bn = 128 (default) or 64 (skinny LoRA-down GEMMs)

@@ -160,6 +160,7 @@ void gemm_init() {
     set_attr<128, EPI_PATCH_FWD>();
     set_attr<128, EPI_PATCH_BWD>();
     set_attr<128, EPI_STORE_F32>();
+    set_attr<128, EPI_DROP_ACC>();
     gemm256_init();
     const char* e = getenv("VITLORA_GEMM128");      // A/B switch: force the 128-row kernel
     g_force_small = (e && e[0] == '1') ? 1 : 0;
@@ -196,5 +197,6 @@ void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
         case EPI_PATCH_FWD: launch_t<128, EPI_PATCH_FWD>(a, s); break;
         case EPI_PATCH_BWD: launch_t<128, EPI_PATCH_BWD>(a, s); break;
         case EPI_STORE_F32: launch_t<128, EPI_STORE_F32>(a, s); break;
+        case EPI_DROP_ACC: launch_t<128, EPI_DROP_ACC>(a, s); break;
     }
 }

@@ -327,7 +327,7 @@ void set_attr() { set_attr1<256, EPI>(); set_attr1<128, EPI>(); }
 }  // namespace
 
 bool gemm256_supports(const GemmArgs& a, int epi) {
-    if (a.a_gather) return false;          // the patch-gradient GEMM (row-gathered A) stays on the 128-row kernel
+    if (a.a_gather || epi == EPI_DROP_ACC) return false;   // row-gathered A / masked accumulate stay on the 128-row kernel
     if (a.N % BN || a.M % 128 || a.K1 % BK || a.K2 % BK) return false;
     if ((a.K1 + a.K2) / BK < 2) return false;
     int nb, ns;

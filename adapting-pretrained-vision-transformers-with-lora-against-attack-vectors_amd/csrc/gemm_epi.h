@@ -50,6 +50,19 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = f2bf(v[i] * bf2f(z[i]));
         *(bf16x4*)((bf16*)p.C + (size_t)m * p.ldc + n) = o;
+    } else if constexpr (EPI == EPI_DROP_ACC) {
+        // d(input) = R + mask * (u (sA)) [* gelu'(z)]: the LoRA branch saw the dropped input
+        const bf16x4 r = *(const bf16x4*)((const bf16*)p.R + (size_t)m * p.ldr + n);
+        bf16x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float ms = drop_scale(p.drop_seed, p.drop_stream, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + i),
+                                        p.drop_p, p.drop_inv_keep);
+            float t = bf2f(r[i]) + ms * v[i];
+            if (p.G) t *= bf2f(p.G[(size_t)m * p.ldg + n + i]);
+            o[i] = f2bf(t);
+        }
+        *(bf16x4*)((bf16*)p.C + (size_t)m * p.ldc + n) = o;
     } else if constexpr (EPI == EPI_PATCH_FWD) {
         if (m < p.Mvalid) {
             const int b = m / p.patches, pi = m - b * p.patches;

@@ -31,6 +31,8 @@ void k_pack_bf16_t(const float* src, bf16* dst, int rows, int cols, int ldd, int
 void k_merge_lora(const float* W, const float* A, const float* B, int out, int in, int r, float sc, bf16* dst, int ldd,
                   int roff, bf16* dstT, int lddT, int coffT, hipStream_t s);
 
+void k_dropout(const bf16* x, bf16* xd, int64_t n, uint64_t seed, uint32_t stream, float p, hipStream_t s);
+void k_dropout_mask(float* out, int64_t n, uint64_t seed, uint32_t stream, float p, hipStream_t s);
 void k_merge_f32(const float* W, const float* A, const float* B, int out, int in, int r, float sc, float* dst,
                  hipStream_t s);
 

@@ -81,6 +81,7 @@ struct Workspace {
     float *xhat, *xf, *rstd_f, *logits, *dlogits, *loss;
     float* dres[2];
     bf16 *dres_bf, *dh, *dctx, *dqkv, *dz, *u;
+    bf16* xd;                        // train mode: dropout(x) of the current LoRA branch / dgrad temporary [Mpad, MLP]
     float* grad_img;                 // [max_batch, 3, S, S] for vl_pgd_attack
 };
 
@@ -102,6 +103,7 @@ struct vl_model {
     Workspace ws;
     // state of the last forward
     int cur_B = 0, cur_M = 0, cur_norm = 0, cur_train = 0, have_loss = 0;
+    uint64_t drop_seed = 0x5eed, drop_base = 0x5eed, drop_calls = 0;   // LoRA dropout: seed of the last train-mode forward
     // PGD graph cache
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t cap_stream = nullptr;
@@ -137,13 +139,22 @@ void add_ext(GemmArgs& g, const bf16* A2, int lda2, const bf16* W2, int ldw2, in
     g.A2 = A2; g.lda2 = lda2; g.W2 = W2; g.ldw2 = ldw2; g.K2 = K2;
 }
 
+bool drop_on(const vl_model* m) { return m->cur_train && m->r && m->cfg.lora_dropout > 0.f; }
+
 // y = x W^T (+ LoRA) with epilogue; `t` receives the LoRA down projection when fused.
-void linear_fwd(vl_model* m, const Linear& ln, const bf16* x, bf16* t, int Mpad, GemmArgs g, int epi, hipStream_t s) {
+// stream_id = layer*4 + projection: names the dropout mask of this projection's LoRA branch input.
+void linear_fwd(vl_model* m, const Linear& ln, const bf16* x, bf16* t, int Mpad, GemmArgs g, int epi, hipStream_t s,
+                uint32_t stream_id) {
     g.A1 = x; g.lda1 = ln.in; g.W1 = ln.W; g.ldw1 = ln.in; g.K1 = ln.in;
     g.M = Mpad; g.N = ln.out; g.bias = ln.bias;
     g.Mvalid = m->cur_M;
     if (ln.kext && !m->cfg.lora_merged) {
-        GemmArgs d = gemm_args(x, ln.in, ln.Ad, ln.in, ln.in, Mpad, ln.kext);
+        const bf16* xb = x;                  // LoRA branch input: dropout(x) in train mode (peft Linear.forward)
+        if (drop_on(m)) {
+            k_dropout(x, m->ws.xd, (int64_t)m->cur_M * ln.in, m->drop_seed, stream_id, m->cfg.lora_dropout, s);
+            xb = m->ws.xd;
+        }
+        GemmArgs d = gemm_args(xb, ln.in, ln.Ad, ln.in, ln.in, Mpad, ln.kext);
         d.Mvalid = m->cur_M; d.n_algo = m->r * (int)ln.slots.size();
         g.k2_algo = m->r;      // each output column sees r LoRA columns
         d.C = t; d.ldc = ln.kext;
@@ -154,7 +165,8 @@ void linear_fwd(vl_model* m, const Linear& ln, const bf16* x, bf16* t, int Mpad,
 }
 
 // dx = dy W (+ LoRA) with epilogue; `u` receives dy B.
-void linear_dgrad(vl_model* m, const Linear& ln, const bf16* dy, bf16* u, int Mpad, GemmArgs g, int epi, hipStream_t s) {
+void linear_dgrad(vl_model* m, const Linear& ln, const bf16* dy, bf16* u, int Mpad, GemmArgs g, int epi, hipStream_t s,
+                  uint32_t stream_id) {
     g.A1 = dy; g.lda1 = ln.out; g.W1 = ln.WT; g.ldw1 = ln.out; g.K1 = ln.out;
     g.M = Mpad; g.N = ln.in; g.bias = nullptr;
     g.Mvalid = m->cur_M;
@@ -162,9 +174,24 @@ void linear_dgrad(vl_model* m, const Linear& ln, const bf16* dy, bf16* u, int Mp
         GemmArgs d = gemm_args(dy, ln.out, ln.Bd, ln.out, ln.out, Mpad, ln.kext);
         // u = dy B: each of the r*slots columns sums over its own module's `out` rows only
         d.Mvalid = m->cur_M; d.n_algo = m->r; 
-        g.k2_algo = m->r * (int)ln.slots.size();
         d.C = u; d.ldc = ln.kext;
         launch_gemm(d, EPI_STORE_BF16, 64, s);
+        if (drop_on(m)) {
+            // the LoRA branch saw dropout(x): d(x) = dy W + mask * (u (sA)), then the caller's epilogue factor.
+            // two launches: the frozen part into a temporary, then the masked rank-r part on top of it.
+            GemmArgs main = g;
+            main.C = m->ws.xd; main.ldc = ln.in; main.R = nullptr; main.C2 = nullptr;
+            launch_gemm(main, EPI_STORE_BF16, 128, s);
+            GemmArgs lo = gemm_args(u, ln.kext, ln.Au, ln.kext, ln.kext, Mpad, ln.in);
+            lo.Mvalid = m->cur_M; lo.k2_algo = 0;
+            lo.C = g.C; lo.ldc = g.ldc; lo.R = m->ws.xd; lo.ldr = ln.in;
+            if (epi == EPI_GELU_BWD) { lo.G = (const bf16*)g.R; lo.ldg = g.ldr; }
+            lo.drop_seed = m->drop_seed; lo.drop_stream = stream_id; lo.drop_p = m->cfg.lora_dropout;
+            lo.drop_inv_keep = 1.f / (1.f - m->cfg.lora_dropout);
+            launch_gemm(lo, EPI_DROP_ACC, 128, s);
+            return;
+        }
+        g.k2_algo = m->r * (int)ln.slots.size();
         add_ext(g, u, ln.kext, ln.Au, ln.kext, ln.kext);
     }
     launch_gemm(g, epi, 128, s);
@@ -449,6 +476,7 @@ static size_t carve(vl_model* m, int B, int train, char* base) {
     w.dqkv = (bf16*)take((size_t)Mpad * 3 * D * 2);
     w.dz = (bf16*)take((size_t)Mpad * MLP * 2);
     w.u = (bf16*)take((size_t)Mpad * kext_max * 2);
+    w.xd = train ? (bf16*)take((size_t)Mpad * MLP * 2) : nullptr;
     w.grad_img = (float*)take((size_t)B * 3 * m->S * m->S * 4);
     return off;
 }
@@ -483,12 +511,13 @@ static int forward_impl(vl_model* m, const float* x, int B, int normalise, int t
     if (B <= 0 || B > w.max_batch) return fail(VL_ERR_STATE, "batch %d exceeds planned workspace (%d)", B, w.max_batch);
     if (train && !w.train) return fail(VL_ERR_STATE, "workspace was not planned for training");
     if (train && m->cfg.lora_merged) return fail(VL_ERR_STATE, "training needs lora_merged = 0");
-    if (train && m->r && m->cfg.lora_dropout > 0.f)
-        return fail(VL_ERR_UNSUPPORTED, "lora_dropout > 0 in train mode is not implemented yet");
+    if (train && m->r && m->cfg.lora_dropout >= 1.f) return fail(VL_ERR_ARG, "lora_dropout must be < 1");
     const int D = m->D, L = m->L, T = m->T;
     const int Mpad = (int)round_up((int64_t)B * T, 128), Mppad = (int)round_up((int64_t)B * m->NP, 128);
     const int M = B * T;
     m->cur_M = M;
+    m->cur_train = train;
+    if (train) m->drop_seed = m->drop_base + (++m->drop_calls);
     k_patch_gather(x, w.patches, B, m->S, m->P, normalise, m->mean, m->stdv, s);
     {
         GemmArgs g = gemm_args(w.patches, m->PK, m->Wpe, m->PK, m->PK, Mppad, D);
@@ -502,16 +531,16 @@ static int forward_impl(vl_model* m, const float* x, int B, int normalise, int t
         GemmArgs g;
         k_layernorm_fwd(w.xs[2 * l], w.h1[l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, ly.ln1_b, M, D, m->cfg.ln_eps, s);
         memset(&g, 0, sizeof g); g.C = w.qkv[l]; g.ldc = 3 * D;
-        linear_fwd(m, ly.lin[LQKV], w.h1[l], w.t[LQKV][l], Mpad, g, EPI_STORE_BF16, s);
+        linear_fwd(m, ly.lin[LQKV], w.h1[l], w.t[LQKV][l], Mpad, g, EPI_STORE_BF16, s, l * 4 + LQKV);
         if ((m->attn16 ? k_attention_fwd : k_attention32_fwd)(w.qkv[l], w.ctx[l], w.lse[l], B, T, m->H, D, s)) return fail(VL_ERR_UNSUPPORTED, "attention: T > 224");
         memset(&g, 0, sizeof g); g.C = w.xs[2 * l + 1]; g.ldc = D; g.R = w.xs[2 * l]; g.ldr = D;
-        linear_fwd(m, ly.lin[LO], w.ctx[l], w.t[LO][l], Mpad, g, EPI_RESID_F32, s);
+        linear_fwd(m, ly.lin[LO], w.ctx[l], w.t[LO][l], Mpad, g, EPI_RESID_F32, s, l * 4 + LO);
         k_layernorm_fwd(w.xs[2 * l + 1], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D,
                         m->cfg.ln_eps, s);
         memset(&g, 0, sizeof g); g.C = w.a[l]; g.ldc = m->MLP; g.C2 = w.z[l]; g.ldc2 = m->MLP;
-        linear_fwd(m, ly.lin[LFC1], w.h2[l], w.t[LFC1][l], Mpad, g, EPI_GELU, s);
+        linear_fwd(m, ly.lin[LFC1], w.h2[l], w.t[LFC1][l], Mpad, g, EPI_GELU, s, l * 4 + LFC1);
         memset(&g, 0, sizeof g); g.C = w.xs[2 * l + 2]; g.ldc = D; g.R = w.xs[2 * l + 1]; g.ldr = D;
-        linear_fwd(m, ly.lin[LFC2], w.a[l], w.t[LFC2][l], Mpad, g, EPI_RESID_F32, s);
+        linear_fwd(m, ly.lin[LFC2], w.a[l], w.t[LFC2][l], Mpad, g, EPI_RESID_F32, s, l * 4 + LFC2);
     }
     k_head_fwd(w.xs[2 * L], B, T, D, m->C, m->cfg.ln_eps, m->lnf_g, m->lnf_b, m->flat + m->cls_w_off,
                m->flat + m->cls_b_off, w.xhat, w.xf, w.rstd_f, w.logits, s);
@@ -561,8 +590,12 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
     k_head_bwd(w.dlogits, m->flat + m->cls_w_off, m->lnf_g, w.xhat, w.rstd_f, B, T, D, m->C, w.dres[0], w.dres_bf, s);
 
     // LoRA weight gradients of one projection: dy [M,out], x [M,in], t/u [M,kext]
-    auto wgrad = [&](const Linear& ln, const bf16* dy, const bf16* x, const bf16* t, const bf16* u) {
+    auto wgrad = [&](const Linear& ln, const bf16* dy, const bf16* x, const bf16* t, const bf16* u, uint32_t stream_id) {
         if (!flat_grad || ln.slots.empty()) return;
+        if (drop_on(m)) {       // dA sees the dropped branch input: regenerate it (same seed / stream as the forward)
+            k_dropout(x, w.xd, (int64_t)M * ln.in, m->drop_seed, stream_id, m->cfg.lora_dropout, s);
+            x = w.xd;
+        }
         for (const Slot& sl : ln.slots) {
             // dB[n][j] = s * sum_m dy[m][row_off+n] * t[m][ext_off+j]
             k_lora_wgrad(dy + sl.row_off, ln.out, sl.out, t + sl.ext_off, ln.kext, r, M, sc, flat_grad + sl.b_off, r, 0,
@@ -577,23 +610,23 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
         GemmArgs g;
         // MLP: dz = (dx2 Wfc2 (+LoRA)) * gelu'(z)
         memset(&g, 0, sizeof g); g.C = w.dz; g.ldc = MLP; g.R = w.z[l]; g.ldr = MLP;
-        linear_dgrad(m, ly.lin[LFC2], w.dres_bf, w.u, Mpad, g, EPI_GELU_BWD, s);
-        wgrad(ly.lin[LFC2], w.dres_bf, w.a[l], w.t[LFC2][l], w.u);
+        linear_dgrad(m, ly.lin[LFC2], w.dres_bf, w.u, Mpad, g, EPI_GELU_BWD, s, l * 4 + LFC2);
+        wgrad(ly.lin[LFC2], w.dres_bf, w.a[l], w.t[LFC2][l], w.u, l * 4 + LFC2);
         memset(&g, 0, sizeof g); g.C = w.dh; g.ldc = D;
-        linear_dgrad(m, ly.lin[LFC1], w.dz, w.u, Mpad, g, EPI_STORE_BF16, s);
-        wgrad(ly.lin[LFC1], w.dz, w.h2[l], w.t[LFC1][l], w.u);
+        linear_dgrad(m, ly.lin[LFC1], w.dz, w.u, Mpad, g, EPI_STORE_BF16, s, l * 4 + LFC1);
+        wgrad(ly.lin[LFC1], w.dz, w.h2[l], w.t[LFC1][l], w.u, l * 4 + LFC1);
         k_layernorm_bwd(w.dh, w.xs[2 * l + 1], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, w.dres[cur], w.dres[cur ^ 1],
                         w.dres_bf, M, D, s);
         cur ^= 1;
         // attention block
         memset(&g, 0, sizeof g); g.C = w.dctx; g.ldc = D;
-        linear_dgrad(m, ly.lin[LO], w.dres_bf, w.u, Mpad, g, EPI_STORE_BF16, s);
-        wgrad(ly.lin[LO], w.dres_bf, w.ctx[l], w.t[LO][l], w.u);
+        linear_dgrad(m, ly.lin[LO], w.dres_bf, w.u, Mpad, g, EPI_STORE_BF16, s, l * 4 + LO);
+        wgrad(ly.lin[LO], w.dres_bf, w.ctx[l], w.t[LO][l], w.u, l * 4 + LO);
         if ((m->attn16 ? k_attention_bwd : k_attention32_bwd)(w.qkv[l], w.ctx[l], w.dctx, w.lse[l], w.dqkv, B, T, m->H, D, s))
             return fail(VL_ERR_UNSUPPORTED, "attention: T > 224");
         memset(&g, 0, sizeof g); g.C = w.dh; g.ldc = D;
-        linear_dgrad(m, ly.lin[LQKV], w.dqkv, w.u, Mpad, g, EPI_STORE_BF16, s);
-        wgrad(ly.lin[LQKV], w.dqkv, w.h1[l], w.t[LQKV][l], w.u);
+        linear_dgrad(m, ly.lin[LQKV], w.dqkv, w.u, Mpad, g, EPI_STORE_BF16, s, l * 4 + LQKV);
+        wgrad(ly.lin[LQKV], w.dqkv, w.h1[l], w.t[LQKV][l], w.u, l * 4 + LQKV);
         k_layernorm_bwd(w.dh, w.xs[2 * l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, w.dres[cur], w.dres[cur ^ 1], w.dres_bf,
                         M, D, s);
         cur ^= 1;
@@ -637,6 +670,22 @@ int vl_channel_affine(float* dst, const float* src, const float scale[3], const 
                       void* stream) {
     if (!dst || !src || !scale || !shift || batch <= 0 || hw <= 0) return fail(VL_ERR_ARG, "bad argument");
     k_channel_affine(dst, src, scale, shift, batch, hw, (hipStream_t)stream);
+    return VL_OK;
+}
+
+int vl_set_dropout_seed(vl_model* m, uint64_t seed) {
+    if (!m) return fail(VL_ERR_ARG, "null model");
+    m->drop_base = seed; m->drop_calls = 0;
+    return VL_OK;
+}
+
+// keep-mask (0 or 1/(1-p)) that the last train-mode forward applied to the LoRA branch input of
+// projection `proj` (0 = fused qkv, 1 = attention out, 2 = fc1, 3 = fc2) of `layer`: [B*T, in] fp32.
+int vl_dropout_mask(vl_model* m, int layer, int proj, float* out, void* stream) {
+    if (!m || !out || layer < 0 || layer >= m->L || proj < 0 || proj > 3) return fail(VL_ERR_ARG, "bad argument");
+    if (!m->cur_train || !(m->cfg.lora_dropout > 0.f)) return fail(VL_ERR_STATE, "no train-mode forward with dropout");
+    k_dropout_mask(out, (int64_t)m->cur_M * m->layers[layer].lin[proj].in, m->drop_seed, (uint32_t)(layer * 4 + proj),
+                   m->cfg.lora_dropout, (hipStream_t)stream);
     return VL_OK;
 }
 

@@ -272,6 +272,18 @@ class Engine:
                                     C.c_void_p(m2.data_ptr()), float(lr), float(b1), float(b2), float(eps), int(t),
                                     param.numel(), self._stream()), "vl_adam_step")
 
+    def set_dropout_seed(self, seed: int):
+        check(self.lib.vl_set_dropout_seed(self.h, int(seed)), "vl_set_dropout_seed")
+
+    def dropout_mask(self, layer: int, proj: str, batch: int) -> torch.Tensor:
+        """Keep-mask (0 or 1/(1-p)) the last train-mode forward used for `proj` in
+        {"qkv","o","fc1","fc2"} of `layer`: [batch, tokens, in]."""
+        pi = {"qkv": 0, "o": 1, "fc1": 2, "fc2": 3}[proj]
+        cols = self.arch.mlp if proj == "fc2" else self.arch.hidden
+        out = torch.empty(batch, self.arch.tokens, cols, dtype=torch.float32, device=self.device)
+        check(self.lib.vl_dropout_mask(self.h, layer, pi, C.c_void_p(out.data_ptr()), self._stream()), "vl_dropout_mask")
+        return out
+
     def quantize_u8(self, images: torch.Tensor) -> torch.Tensor:
         images = self._f32(images)
         B, Cn, H, W = images.shape

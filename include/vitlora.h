@@ -121,6 +121,16 @@ int vl_set_dlogits(vl_model* m, const float* dlogits, void* stream);
 /* One backward pass producing both gradients; either output may be NULL. */
 int vl_backward(vl_model* m, float* grad_x_out, float* flat_grad_out, void* stream);
 
+/* LoRA dropout (LoraConfig.lora_dropout, train_loras.py:88; active only in vl_forward(train=1)):
+ * the keep-mask of a LoRA branch input is a pure function of (seed, layer, projection, element),
+ * regenerated by the dgrad and wgrad kernels instead of being stored; q, k, v share the mask of
+ * the fused QKV projection's input.  The seed advances by one per train-mode forward.
+ * vl_dropout_mask writes the mask (0 or 1/(1-p)) the LAST train-mode forward used for projection
+ * proj (0 fused qkv, 1 attention out, 2 fc1, 3 fc2) of `layer`: [B*T, in] fp32 -- parity tests
+ * feed it to the oracle. */
+int vl_set_dropout_seed(vl_model* m, uint64_t seed);
+int vl_dropout_mask(vl_model* m, int layer, int proj, float* out, void* stream);
+
 /* loss.backward() restricted to the input: dLoss/dx [B,3,S,S] fp32 in the space of
  * the x given to vl_forward (perturbed.grad, whitebox_attacks.py:30-32). */
 int vl_backward_input(vl_model* m, float* grad_x_out, void* stream);
@@ -167,6 +177,10 @@ int vl_channel_affine(float* dst, const float* src, const float scale[3], const 
  * "bytes": algorithmic}, ...} into buf. */
 int vl_profile_begin(void);
 int vl_profile_report(char* buf, size_t cap);
+
+/* GEMM micro-benchmark (tools/gemm_sweep.py): random bf16 operands allocated internally, `iters`
+ * launches timed with HIP events; epi = GemmEpilogue of csrc/gemm.h (+100: all rows stored to row 0). */
+int vl_bench_gemm(int M, int N, int K1, int K2, int epi, int bn, int iters, float* ms_out);
 
 /* Introspection for tests / profiling. */
 int vl_debug_tensor(vl_model* m, const char* what, int layer, void** ptr, int64_t* numel, int* dtype);

@@ -232,7 +232,8 @@ def lora_linear(x, W, b, ab, scaling, sim=False, drop_mask=None):
 
 def vit_forward(w: Dict[str, torch.Tensor], cfg: OracleConfig, x_norm: torch.Tensor,
                 lora: Optional[OracleLora] = None, sim_bf16: bool = False,
-                return_hidden: bool = False, trace: Optional[dict] = None):
+                return_hidden: bool = False, trace: Optional[dict] = None,
+                drop_masks: Optional[dict] = None):
     """logits [B, C] from already-normalised pixels [B, 3, H, W].  ``trace`` (a dict)
     receives the intermediate tensors the HIP path exposes through vl_debug_tensor."""
     sim = sim_bf16
@@ -259,7 +260,12 @@ def vit_forward(w: Dict[str, torch.Tensor], cfg: OracleConfig, x_norm: torch.Ten
 
         def lin(short, inp):
             k = p + dict(LINEAR_MODULES)[short]
-            return lora_linear(inp, w[k + ".weight"], w[k + ".bias"], ab(i, short), sc, sim)
+            # train-mode LoRA dropout: explicit keep-masks (0 or 1/(1-p)) keyed by (layer, projection);
+            # q, k, v share the mask of the fused qkv projection's input
+            dm = None
+            if drop_masks is not None:
+                dm = drop_masks.get((i, "qkv" if short in ("q", "k", "v") else short))
+            return lora_linear(inp, w[k + ".weight"], w[k + ".bias"], ab(i, short), sc, sim, dm)
 
         h = _rb(F.layer_norm(x, (D,), w[p + "layernorm_before.weight"],
                              w[p + "layernorm_before.bias"], cfg.ln_eps), sim)
@@ -356,7 +362,7 @@ def pgd_torchattacks_compat(w, cfg, x01, labels, eps, alpha, steps, lora=None, n
 # LoRA training step, Adam, image quantisation
 # ----------------------------------------------------------------------------
 def lora_train_grads(w, cfg, x_norm, labels, lora: OracleLora, sim_bf16=False,
-                     train_classifier=True):
+                     train_classifier=True, drop_masks=None):
     """Gradients of mean CE w.r.t. every LoRA A, B (and the classifier, which peft
     keeps trainable for SEQ_CLS) -- the backward of train_loras.py:310-314."""
     leaves = {}
@@ -372,7 +378,7 @@ def lora_train_grads(w, cfg, x_norm, labels, lora: OracleLora, sim_bf16=False,
         w2["classifier.bias"] = w["classifier.bias"].clone().requires_grad_(True)
         leaves[("cls", "weight")] = w2["classifier.weight"]
         leaves[("cls", "bias")] = w2["classifier.bias"]
-    logits = vit_forward(w2, cfg, x_norm, lr, sim_bf16)
+    logits = vit_forward(w2, cfg, x_norm, lr, sim_bf16, drop_masks=drop_masks)
     loss = F.cross_entropy(logits, labels)
     grads = torch.autograd.grad(loss, list(leaves.values()))
     return loss.detach(), logits.detach(), dict(zip(leaves.keys(), grads))

@@ -188,6 +188,42 @@ def test_lora_train_grads():
         assert rel_l2(got, grads[("cls", which)]) < 1e-2
 
 
+def test_lora_dropout_train_mode_matches_oracle_with_same_masks():
+    """lora_dropout > 0 (the reference trains with 0.1, train_loras.py:79): the HIP path's masks are
+    read back and handed to the oracle, so the stochastic op is checked exactly."""
+    cfg, w, lora, x, y = make_case(batch=4, targets=("q", "k", "v", "o", "fc1", "fc2"))
+    p = 0.25
+    eng = make_engine(cfg, w, lora, dropout=p)
+    eng.set_dropout_seed(77)
+    xn = O.normalise(x)
+    logits = eng.forward(xn.cuda(), normalise=False, train=True)
+    loss = eng.loss_ce(y.cuda())
+    masks = {(l, pr): eng.dropout_mask(l, pr, 4).cpu() for l in range(cfg.layers) for pr in ("qkv", "o", "fc1", "fc2")}
+    gx, gp = eng.backward(True, True, tuple(x.shape))
+    torch.cuda.synchronize()
+    m0 = masks[(0, "qkv")]
+    keep = (m0 > 0).float().mean().item()
+    assert abs(keep - (1 - p)) < 0.02 and torch.allclose(m0[m0 > 0], torch.tensor(1 / (1 - p)))
+    assert not torch.equal(masks[(0, "qkv")], masks[(1, "qkv")]) and not torch.equal(masks[(0, "qkv")], masks[(0, "o")])
+    l_ref, lg_ref, grads = O.lora_train_grads(w, cfg, xn, y, lora, drop_masks=masks)
+    assert rel_l2(logits.cpu(), lg_ref) < TOL_FP32
+    # without the masks the oracle must NOT match: the masks really were applied
+    assert rel_l2(logits.cpu(), O.vit_forward(w, cfg, xn, lora)) > 1.5 * rel_l2(logits.cpu(), lg_ref)
+    base = eng.flat.data_ptr()
+    for i in range(cfg.layers):
+        for t in lora.targets:
+            for which in ("A", "B"):
+                v = eng.param(i, t, which)
+                off = (v.data_ptr() - base) // 4
+                got = gp[off:off + v.numel()].view(v.shape).cpu()
+                assert rel_l2(got, grads[(which, i, t)]) < 3e-2, (i, t, which)
+    # a new forward draws new masks; eval-mode forward ignores dropout
+    eng.forward(xn.cuda(), normalise=False, train=True)
+    assert not torch.equal(eng.dropout_mask(0, "qkv", 4).cpu(), m0)
+    ev = eng.forward(xn.cuda(), normalise=False, train=False).cpu()
+    assert rel_l2(ev, O.vit_forward(w, cfg, xn, lora)) < TOL_FP32
+
+
 def test_adam_and_quantiser():
     torch.manual_seed(1)
     cfg, w, lora, x, y = make_case(batch=1, r=0)
