@@ -20,14 +20,16 @@ void gemm256_init();
 
 namespace {
 
-constexpr int BM = 128;
 constexpr int BK = 64;
 
-template <int BN, int EPI>
+// STAGES = LDS ring depth: 2 (one K step ahead, drained every step) or 4 (three K steps of
+// direct-to-LDS loads in flight behind a counted vmcnt: the skinny LoRA-down products are pure
+// HBM streams and need the bytes in flight, not the MFMA rate).
+template <int BM, int BN, int EPI, int STAGES = 2>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* sA = (bf16*)smem;              // [2][BM][BK]
-    bf16* sW = sA + 2 * BM * BK;         // [2][BN][BK]
+    bf16* sA = (bf16*)smem;                   // [STAGES][BM][BK]
+    bf16* sW = sA + STAGES * BM * BK;         // [STAGES][BN][BK]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tilesN = p.N / BN;
@@ -36,11 +38,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
     const int bm = id / tilesN, bn = id - bm * tilesN;
     const int wm = w >> 1, wn = w & 1;
     constexpr int NJ = BN / 32;          // 16-wide column tiles per wave
+    constexpr int MI = BM / 32;          // 16-high row tiles per wave
     constexpr int WG = BN / 32;          // 8-row load groups of the W tile per wave
+    constexpr int AG = BM / 32;          // 8-row load groups of the A tile per wave
 
-    f32x4 acc[4][NJ];
+    f32x4 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -50,10 +54,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
     const int lc = lane & 7;             // 16-byte chunk position inside the 128-byte row
 
     // per-lane A rows of the 4 load groups (fixed over the K loop)
-    size_t arow[4];
+    size_t arow[AG];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int m = bm * BM + (w * 4 + i) * 8 + lr;
+    for (int i = 0; i < AG; ++i) {
+        int m = bm * BM + (w * AG + i) * 8 + lr;
         if (p.a_gather) m = m < p.Mvalid ? m + m / p.patches + 1 : 0;
         arow[i] = (size_t)m;
     }
@@ -65,8 +69,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
         bf16* dA = sA + buf * BM * BK;
         bf16* dW = sW + buf * BN * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int g = w * 4 + i;
+        for (int i = 0; i < AG; ++i) {
+            const int g = w * AG + i;
             const int r = g * 8 + lr;
             const int c = lc ^ (r & 7);
             glds16(Ap + arow[i] * lda + k0 + c * 8, dA + g * 8 * BK);
@@ -80,20 +84,33 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
         }
     };
 
-    issue(0, 0);
     const int fr = lane & 15, fg = lane >> 4;
+    constexpr int LPS = AG + WG;              // load instructions per wave per stage
+#pragma unroll
+    for (int st = 0; st < STAGES - 1; ++st)
+        if (st < nk) issue(st, st);
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        const bf16* cA = sA + (kt & 1) * BM * BK;
-        const bf16* cW = sW + (kt & 1) * BN * BK;
+        // stage kt landed (in every wave after the barrier); later stages stay in flight
+        if constexpr (STAGES == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            const int ahead = min(nk - 1, kt + STAGES - 2) - kt;     // stages issued after stage kt
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+        const bf16* cA = sA + (kt % STAGES) * BM * BK;
+        const bf16* cW = sW + (kt % STAGES) * BN * BK;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], wf[NJ];
+            bf16x8 af[MI], wf[NJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = wm * 64 + i * 16 + fr;
+            for (int i = 0; i < MI; ++i) {
+                const int r = wm * (BM / 2) + i * 16 + fr;
                 const int c = (ks * 4 + fg) ^ (r & 7);
                 af[i] = *(const bf16x8*)(cA + r * BK + c * 8);
             }
@@ -104,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
                 wf[j] = *(const bf16x8*)(cW + r * BK + c * 8);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);   // D[n][m]: lane owns 4 consecutive n
@@ -121,8 +138,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
             bv[j] = *(const f32x4*)(p.bias + bn * BN + wn * (BN / 2) + j * 16 + fg * 4);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = bm * BM + wm * 64 + i * 16 + fr;
+    for (int i = 0; i < MI; ++i) {
+        const int m = bm * BM + wm * (BM / 2) + i * 16 + fr;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = bn * BN + wn * (BN / 2) + j * 16 + fg * 4;
@@ -131,17 +148,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
     }
 }
 
-template <int BN, int EPI>
+template <int BN, int EPI, int BM = 128, int STAGES = 2>
 void launch_t(const GemmArgs& a, hipStream_t s) {
     const int ntiles = (a.M / BM) * (a.N / BN);
-    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16);
-    hipLaunchKernelGGL((gemm_nt_kernel<BN, EPI>), dim3(ntiles), dim3(256), lds, s, a);
+    const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(bf16);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, EPI, STAGES>), dim3(ntiles), dim3(256), lds, s, a);
 }
 
-template <int BN, int EPI>
+template <int BN, int EPI, int BM = 128, int STAGES = 2>
 void set_attr() {
-    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(bf16);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, EPI, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
 int g_force_small = -1;
@@ -153,6 +170,8 @@ void gemm_init() {
     static bool done = false;
     if (done) return;
     set_attr<64, EPI_STORE_BF16>();
+    set_attr<64, EPI_STORE_BF16, 64, 4>();
+    set_attr<64, EPI_STORE_BF16, 128, 2>();
     set_attr<128, EPI_STORE_BF16>();
     set_attr<128, EPI_RESID_F32>();
     set_attr<128, EPI_GELU>();
@@ -181,11 +200,12 @@ void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
         launch_gemm256(b, epi, s);
         return;
     }
-    snprintf(name, sizeof name, "gemm_nt_kernel<%d, %d>", bn == 64 ? 64 : 128, epi);
+    snprintf(name, sizeof name, "gemm_nt_kernel<128, %d, %d>", bn == 64 ? 64 : 128, epi);
     ProfScope prof_(name, flops, 0.0, s);
     if (bn == 64) {
         switch (epi) {
-            case EPI_STORE_BF16: launch_t<64, EPI_STORE_BF16>(a, s); return;
+            // skinny LoRA-down product (HBM-bound on A): 64-row tiles -> 3x more workgroups in flight
+            case EPI_STORE_BF16: launch_t<64, EPI_STORE_BF16, 128, 2>(a, s); return;
             default: break;
         }
     }

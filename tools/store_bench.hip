@@ -3,6 +3,7 @@
 // (b) same rows but the two 16 B pieces of a lane quad contiguous (64 B runs), (c) fully coalesced.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int MODE>
 __global__ __launch_bounds__(512) void k(char* out, int ld_bytes, int tiles_per_wg, int tilesN) {
@@ -36,7 +37,8 @@ __global__ __launch_bounds__(512) void k(char* out, int ld_bytes, int tiles_per_
         }
     }
 }
-int main() {
+int main(int argc, char** argv) {
+    const int G = argc > 1 ? atoi(argv[1]) : 256;
     const int M = 50432, N = 3072, tilesN = N / 256, ntiles = (M / 256) * tilesN;
     char* out; hipMalloc(&out, (size_t)M * N * 2);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -44,14 +46,14 @@ int main() {
         float best = 1e9;
         for (int rep = 0; rep < 5; ++rep) {
             hipEventRecord(e0);
-            if (mode == 0) k<0><<<256, 512>>>(out, N * 2, ntiles / 256, tilesN);
-            if (mode == 1) k<1><<<256, 512>>>(out, N * 2, ntiles / 256, tilesN);
-            if (mode == 2) k<2><<<256, 512>>>(out, N * 2, ntiles / 256, tilesN);
+            if (mode == 0) k<0><<<G, 512>>>(out, N * 2, 9, tilesN);
+            if (mode == 1) k<1><<<G, 512>>>(out, N * 2, 9, tilesN);
+            if (mode == 2) k<2><<<G, 512>>>(out, N * 2, 9, tilesN);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
         }
-        const double bytes = (double)(ntiles / 256) * 256 * 131072.0;
-        printf("mode %d: %.1f us  %.2f TB/s  (%.1f us per 128KB tile per CU)\n", mode, best * 1e3, bytes / best / 1e9, best * 1e3 / (ntiles / 256));
+        const double bytes = 9.0 * G * 131072.0;
+        printf("mode %d: %.1f us  %.2f TB/s  (%.1f us per 128KB tile per CU)\n", mode, best * 1e3, bytes / best / 1e9, best * 1e3 / 9);
     }
     return 0;
 }
