@@ -1,58 +1,111 @@
 // LoRA weight gradients (train_loras.py:314 loss.backward(), restricted to lora_A / lora_B):
-//   dB[n][j] = s * sum_m dy[m][n] * t[m][j]      (t = x A^T kept from the forward)
+//   dB[n][j] = s * sum_m dy[m][n] * t[m][j]      (t = dropout(x) A^T kept from the forward)
 //   dA[j][k] = s * sum_m u[m][j]  * x[m][k]      (u = dy B  kept from the dgrad)
-// Generic form: Out[i][j] = scale * sum_m L[m][i] * R[m][j] over the M token rows.
-// v1: LDS-staged VALU kernel, M split over workgroups, fp32 atomics into a zeroed output.
+// Generic form: Out[i][j] = scale * sum_m L[m][i] * R[m][j] over the M token rows, L = the wide
+// operand (768..3072 columns), R = the rank-r operand (<= 64 columns).
+//
+// Both operands are token-major, i.e. the summed index m is the ROW of both: each 32-token step
+// is staged into LDS as two swizzled [32][64] bf16 images and BOTH MFMA operands are read with the
+// hardware-transposed ds_read_b64_tr_b16 (same k order on both sides).  A workgroup owns 64 columns
+// of L and a chunk of tokens; partial results are added to the fp32 output with atomics (the
+// output was zeroed by the caller; one add per element per token chunk).  HBM-bound on L.
 #include "kernels.h"
 #include "prof.h"
 
 namespace {
 
-constexpr int MC = 64;    // token rows per workgroup
+constexpr int HD = 64;          // image row length (elements)
+constexpr int MCHUNK = 512;     // tokens per workgroup
 
-__global__ __launch_bounds__(256) void lora_wgrad_kernel(const bf16* __restrict__ L, int ldl, int ncl,
-                                                         const bf16* __restrict__ R, int ldr, int ncr, int M,
-                                                         float scale, float* __restrict__ out, int ldo, int transpose_out) {
-    __shared__ float sL[MC][65];
-    __shared__ float sR[MC][64];
-    const int m0 = blockIdx.x * MC;
-    const int i0 = blockIdx.y * 64, j0 = blockIdx.z * 64;
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < MC * 64; idx += 256) {
-        const int r = idx >> 6, c = idx & 63;
-        const int m = m0 + r;
-        sL[r][c] = (m < M && i0 + c < ncl) ? bf2f(L[(size_t)m * ldl + i0 + c]) : 0.f;
-        sR[r][c] = (m < M && j0 + c < ncr) ? bf2f(R[(size_t)m * ldr + j0 + c]) : 0.f;
-    }
-    __syncthreads();
-    const int il = tid & 63, jq = tid >> 6;
-    float acc[16];
+// transposed fragment of a swizzled [rows][64] image (chunk c of row r at c ^ (r & 7)):
+// element j of lane (fr, fg) = img[r0 + 16*(j>>2) + 4*fg + (j&3)][c0 + fr]
+__device__ __forceinline__ bf16x8 tr_frag16(const bf16* img, int r0, int c0, int fr, int fg) {
+    const int p = fr & 3;
+    const int row = r0 + 4 * fg + (fr >> 2);
+    const int chunk = (c0 >> 3) + (p >> 1);
+    const bf16* a0 = img + row * HD + ((chunk ^ (row & 7)) << 3) + ((p & 1) << 2);
+    const int row1 = row + 16;
+    const bf16* a1 = img + row1 * HD + ((chunk ^ (row1 & 7)) << 3) + ((p & 1) << 2);
+    return cat4(lds_read_tr16(a0), lds_read_tr16(a1));
+}
+
+// NRT = 16-column tiles of R covered (ncr <= 16*NRT)
+template <int NRT>
+__global__ __launch_bounds__(256) void lora_wgrad_mfma_kernel(const bf16* __restrict__ L, int ldl, int ncl,
+                                                              const bf16* __restrict__ R, int ldr, int ncr, int M,
+                                                              float scale, float* __restrict__ out, int ldo,
+                                                              int transpose_out) {
+    __shared__ __attribute__((aligned(16))) bf16 sL[32 * HD];
+    __shared__ __attribute__((aligned(16))) bf16 sR[32 * HD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int i0 = blockIdx.x * 64;                 // first L column of this workgroup
+    const int m_begin = blockIdx.y * MCHUNK;
+    const int m_end = min(M, m_begin + MCHUNK);
+    const int srow = tid >> 3, sc = tid & 7;        // staging: 32 rows x 8 chunks of 16 B
+    const bool l_ok = i0 + sc * 8 < ncl;            // ncl is a multiple of 8 (module widths)
+    const bool r_ok = sc * 8 < ncr;
+    // 16-byte loads of R need r % 8 == 0 and an aligned slot; other ranks (e.g. r = 4) go element-wise
+    const bool r_vec = (ncr % 8 == 0) && (ldr % 8 == 0) && (((size_t)R & 15) == 0);
+
+    f32x4 acc[NRT];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-    for (int r = 0; r < MC; ++r) {
-        const float lv = sL[r][il];
+    for (int t = 0; t < NRT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 zero;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) acc[k] += lv * sR[r][jq * 16 + k];
-    }
-    const int i = i0 + il;
-    if (i < ncl) {
+    for (int k = 0; k < 8; ++k) zero[k] = (bf16)0.f;
+
+    auto load = [&](int m0, bf16x8& lv, bf16x8& rv) {
+        const int m = m0 + srow;
+        lv = zero; rv = zero;
+        if (m < m_end) {
+            if (l_ok) lv = *(const bf16x8*)(L + (size_t)m * ldl + i0 + sc * 8);
+            if (r_ok) {
+                if (r_vec) rv = *(const bf16x8*)(R + (size_t)m * ldr + sc * 8);
+                else {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int j = j0 + jq * 16 + k;
-            if (j < ncr) {
-                float* dst = transpose_out ? out + (size_t)j * ldo + i : out + (size_t)i * ldo + j;
-                atomicAdd(dst, scale * acc[k]);
+                    for (int k = 0; k < 8; ++k)
+                        if (sc * 8 + k < ncr) rv[k] = R[(size_t)m * ldr + sc * 8 + k];
+                }
             }
         }
+    };
+    bf16x8 lv, rv;
+    load(m_begin, lv, rv);
+    for (int m0 = m_begin; m0 < m_end; m0 += 32) {
+        __syncthreads();                            // previous step's fragment reads are done
+        *(bf16x8*)(sL + srow * HD + ((sc ^ (srow & 7)) << 3)) = lv;
+        *(bf16x8*)(sR + srow * HD + ((sc ^ (srow & 7)) << 3)) = rv;
+        __syncthreads();
+        if (m0 + 32 < m_end) load(m0 + 32, lv, rv); // next step's global loads fly under the MFMAs
+        // D[row = j (R column)][col = i (L column)] += sum_m R[m][j] * L[m][i]
+        const bf16x8 lb = tr_frag16(sL, 0, w * 16, fr, fg);
+#pragma unroll
+        for (int t = 0; t < NRT; ++t) acc[t] = mfma16(tr_frag16(sR, 0, t * 16, fr, fg), lb, acc[t]);
+    }
+    const int i = i0 + w * 16 + fr;
+    if (i < ncl) {
+#pragma unroll
+        for (int t = 0; t < NRT; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = t * 16 + 4 * fg + k;
+                if (j < ncr) {
+                    float* dst = transpose_out ? out + (size_t)j * ldo + i : out + (size_t)i * ldo + j;
+                    atomicAdd(dst, scale * acc[t][k]);
+                }
+            }
     }
 }
 
 }  // namespace
 
-void k_lora_wgrad(const bf16* L, int ldl, int ncl, const bf16* R, int ldr, int ncr, int M, float scale, float* out,
+// L: wide operand [M, ncl]; Rm: rank operand [M, ncr <= 64]; out (+)= scale * L^T Rm  (or its transpose)
+void k_lora_wgrad(const bf16* L, int ldl, int ncl, const bf16* Rm, int ldr, int ncr, int M, float scale, float* out,
                   int ldo, int transpose_out, float* /*scratch*/, hipStream_t s) {
-    ProfScope prof_("lora_wgrad_kernel", 2.0 * M * (double)ncl * ncr, 0.0, s);
-    dim3 grid((M + MC - 1) / MC, (ncl + 63) / 64, (ncr + 63) / 64);
-    hipLaunchKernelGGL(lora_wgrad_kernel, grid, dim3(256), 0, s, L, ldl, ncl, R, ldr, ncr, M, scale, out, ldo,
-                       transpose_out);
+    ProfScope prof_("lora_wgrad_mfma_kernel", 2.0 * M * (double)ncl * ncr, (double)M * ncl * 2.0, s);
+    dim3 grid((ncl + 63) / 64, (M + MCHUNK - 1) / MCHUNK);
+    if (ncr <= 16) hipLaunchKernelGGL((lora_wgrad_mfma_kernel<1>), grid, dim3(256), 0, s, L, ldl, ncl, Rm, ldr, ncr, M, scale, out, ldo, transpose_out);
+    else if (ncr <= 32) hipLaunchKernelGGL((lora_wgrad_mfma_kernel<2>), grid, dim3(256), 0, s, L, ldl, ncl, Rm, ldr, ncr, M, scale, out, ldo, transpose_out);
+    else hipLaunchKernelGGL((lora_wgrad_mfma_kernel<4>), grid, dim3(256), 0, s, L, ldl, ncl, Rm, ldr, ncr, M, scale, out, ldo, transpose_out);
 }
