@@ -24,9 +24,11 @@
 //     lets them finish in half a round (same kernel, BM = 128 code path).
 //   * W rows are permuted on the way into LDS so that a lane ends up with 16 ADJACENT output
 //     columns: the epilogue moves 16 bytes per lane per instruction.
+#include <cstdio>
 #include <type_traits>
 
 #include "gemm_epi.h"
+#include "prof.h"
 
 namespace {
 
@@ -303,6 +305,13 @@ bool plan_tiles(int M, int N, int G, int* nbig, int* nsmall) {
 template <int BM, int EPI>
 void launch_one(const GemmArgs& a, int ntiles, int bm0, hipStream_t s) {
     if (ntiles <= 0) return;
+    // one profiling record per actual launch, named like the kernel symbol rocprofv3 reports;
+    // algorithmic FLOPs of this launch = its share of the GEMM's rows
+    char name[64];
+    snprintf(name, sizeof name, "gemm256_kernel<%d, %d>", BM, EPI);
+    const double rows = (double)(ntiles / (a.N / BN)) * BM;
+    const double valid = a.Mvalid ? (double)a.Mvalid / a.M : 1.0;
+    ProfScope prof_(name, 2.0 * rows * valid * (a.n_algo ? a.n_algo : a.N) * (a.K1 + (a.k2_algo ? a.k2_algo : a.K2)), 0.0, s);
     const int grid = ntiles < g_num_cus ? ntiles : g_num_cus;
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16) + 1024;
     hipLaunchKernelGGL((gemm256_kernel<BM, EPI>), dim3(grid), dim3(512), lds, s, a, ntiles, bm0);

@@ -208,7 +208,7 @@ def cpu_baseline(arch, args):
     cfg = O.OracleConfig(num_labels=arch.num_labels)
     w = O.init_weights(cfg, seed=0)
     lora = O.init_lora(cfg, r=args.rank, targets=TARGETS, seed=1)
-    nb, ns = 4, 3
+    nb, ns = 16, 10                      # ~10-20 s of host work on 16 cores
     g = torch.Generator().manual_seed(100)
     x = torch.rand(nb, 3, cfg.image_size, cfg.image_size, generator=g)
     y = torch.randint(0, cfg.num_labels, (nb,), generator=torch.Generator().manual_seed(101))
