@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvitlora_hip.so")
+# VITLORA_LIB: another build of the same library (kernel A/B runs on one GPU box); never a fallback
+LIB_PATH = os.environ.get("VITLORA_LIB") or os.path.join(_HERE, "libvitlora_hip.so")
 
 VL_T = {"q": 1, "k": 2, "v": 4, "o": 8, "fc1": 16, "fc2": 32}
 

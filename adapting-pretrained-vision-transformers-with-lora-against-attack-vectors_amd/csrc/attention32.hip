@@ -14,6 +14,9 @@
 // for S^T = K Q^T, keys for S = Q K^T): the accumulator is then directly the B operand of the
 // following product (k order inside a 16-deep step: 8*(j>>2) + 4*(lane>>5) + (j&3), applied
 // to both operands), and softmax statistics / LSE / delta are per-lane scalars.
+#include <cstdlib>
+#include <cstring>
+
 #include "kernels.h"
 #include "prof.h"
 
@@ -25,6 +28,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// raw v_exp_f32 (no denormal-range fix-up: results below 2^-126 flush to 0, exp2(-inf) = 0)
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ int swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 
 // row fragment of a 32-row tile: lane (r = lane&31, h = lane>>5) gets img[row0 + r][16*ks + 8*h .. +7]
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void attn_fwd32_kernel(const bf16* 
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             if (__any(tmax > m)) {                  // some row's running max grew: rescale (first tile: always)
                 const float mn = fmaxf(m, tmax);    // finite: key 0 of tile 0 is always valid
-                const float alpha = exp2f((m - mn) * scale_log2e);   // first tile: exp2(-inf) = 0, l = 0, o = 0
+                const float alpha = fexp2((m - mn) * scale_log2e);   // first tile: exp2(-inf) = 0, l = 0, o = 0
                 m = mn;
                 l *= alpha;
 #pragma unroll
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void attn_fwd32_kernel(const bf16* 
             const float mc = -m * scale_log2e;
             float ps = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = exp2f(fmaf(s[r], scale_log2e, mc)); ps += s[r]; }
+            for (int r = 0; r < 16; ++r) { s[r] = fexp2(fmaf(s[r], scale_log2e, mc)); ps += s[r]; }
             l += ps;
             // O^T += V^T P^T: rows = d, column = query c
 #pragma unroll
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
                     const f32x4 dl = *(const f32x4*)(sDelta + qt * 32 + 8 * rq + 4 * h);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float p = exp2f(fmaf(s[4 * rq + k], scale_log2e, -lq[k]));   // rows >= T: 0
+                        const float p = fexp2(fmaf(s[4 * rq + k], scale_log2e, -lq[k]));   // rows >= T: 0
                         s[4 * rq + k] = p;
                         dp[4 * rq + k] = p * (dp[4 * rq + k] - dl[k]);     // dS / scale (folded into dK below)
                     }
@@ -296,10 +301,12 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
                     s = mfma32(row_frag32(sK, kt * 32 + c, ks, h), qf[ks], s);        // S^T[key][q]
                     dp = mfma32(row_frag32(sV, kt * 32 + c, ks, h), dof[ks], dp);     // dP^T[key][q]
                 }
+                const bool partial = kt * 32 + 32 > T;      // wave-uniform: only the last key tile is masked
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const float p = key < T ? exp2f(fmaf(s[r], scale_log2e, -lse_q)) : 0.f;
+                    float p = fexp2(fmaf(s[r], scale_log2e, -lse_q));
+                    if (partial && key >= T) p = 0.f;
                     dp[r] = p * (dp[r] - delta_q);                          // dS / scale (folded into dQ below)
                 }
 #pragma unroll

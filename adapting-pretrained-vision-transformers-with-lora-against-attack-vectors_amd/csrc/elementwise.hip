@@ -52,7 +52,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, bf16* __restrict__ h,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            int M, int D, float eps) {
+                                                            int M, int D, float eps, const bf16* __restrict__ delta,
+                                                            float* __restrict__ xout) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -64,8 +65,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
         v[i] = c < nv ? *(const f32x4*)(xr + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (delta && c < nv) {
+            // residual add fused in: x_out = x + delta (the bf16 output of the projection before it)
+            const bf16x4 dl = *(const bf16x4*)(delta + (int64_t)row * D + c * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[i][k] += bf2f(dl[k]);
+            *(f32x4*)(xout + (int64_t)row * D + c * 4) = v[i];
+        }
         s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
+    if (!h) return;                                  // add only (last layer: the head normalises the CLS rows)
     const float mean = wave_sum(s) / D;
     float q = 0.f;
 #pragma unroll
@@ -192,27 +201,32 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 }
 
 // F.cross_entropy(logits, labels), mean reduction; dlogits = (softmax - onehot)/B.
-// single block; one wave per image, round-robin.
+// one wave per image (4 per block) writes the per-image loss; a second tiny launch sums them in a
+// fixed order (bitwise reproducible loss).
 __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                                      int B, int C, float* __restrict__ dlogits, float* __restrict__ loss_out) {
+                                                      int B, int C, float* __restrict__ dlogits, float* __restrict__ loss_img) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* lr = logits + (int64_t)b * C;
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, lr[c]);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int c = lane; c < C; c += 64) se += expf(lr[c] - mx);
+    se = wave_sum(se);
+    const int y = (int)labels[b];
+    const float lse = mx + logf(se);
+    for (int c = lane; c < C; c += 64)
+        dlogits[(int64_t)b * C + c] = (expf(lr[c] - lse) - (c == y ? 1.f : 0.f)) / B;
+    if (lane == 0) loss_img[b] = lse - lr[y];
+}
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict__ loss_img, int B, float* __restrict__ loss_out) {
     __shared__ float red[4];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float lsum = 0.f;
-    for (int b = w; b < B; b += 4) {
-        const float* lr = logits + (int64_t)b * C;
-        float mx = -INFINITY;
-        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, lr[c]);
-        mx = wave_max(mx);
-        float se = 0.f;
-        for (int c = lane; c < C; c += 64) se += expf(lr[c] - mx);
-        se = wave_sum(se);
-        const int y = (int)labels[b];
-        const float lse = mx + logf(se);
-        for (int c = lane; c < C; c += 64)
-            dlogits[(int64_t)b * C + c] = (expf(lr[c] - lse) - (c == y ? 1.f : 0.f)) / B;
-        if (lane == 0) lsum += lse - lr[y];
-    }
-    if (lane == 0) red[w] = lsum;
+    float s = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) s += loss_img[b];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) *loss_out = (red[0] + red[1] + red[2] + red[3]) / B;
 }
@@ -436,15 +450,15 @@ void k_cls_rows(float* x, const float* cls, const float* pos, int B, int T, int 
     hipLaunchKernelGGL(cls_rows_kernel, dim3(nblk((int64_t)B * D, 256)), dim3(256), 0, s, x, cls, pos, B, T, D);
 }
 void k_layernorm_fwd(const float* x, bf16* h, float* mean, float* rstd, const float* g, const float* b, int M, int D,
-                     float eps, hipStream_t s) {
-    ProfScope prof_("layernorm_fwd_kernel", 0.0, (double)M * D * 6.0, s);
+                     float eps, const bf16* delta, float* xout, hipStream_t s) {
+    ProfScope prof_("layernorm_fwd_kernel", 0.0, (double)M * D * (delta ? (h ? 12.0 : 10.0) : 6.0), s);
     const int nv = (D / 4 + 63) / 64;
     dim3 grid((M + 3) / 4), blk(256);
     switch (nv) {
-        case 1: hipLaunchKernelGGL(layernorm_fwd_kernel<1>, grid, blk, 0, s, x, h, mean, rstd, g, b, M, D, eps); break;
-        case 2: hipLaunchKernelGGL(layernorm_fwd_kernel<2>, grid, blk, 0, s, x, h, mean, rstd, g, b, M, D, eps); break;
-        case 3: hipLaunchKernelGGL(layernorm_fwd_kernel<3>, grid, blk, 0, s, x, h, mean, rstd, g, b, M, D, eps); break;
-        default: hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, blk, 0, s, x, h, mean, rstd, g, b, M, D, eps); break;
+        case 1: hipLaunchKernelGGL(layernorm_fwd_kernel<1>, grid, blk, 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout); break;
+        case 2: hipLaunchKernelGGL(layernorm_fwd_kernel<2>, grid, blk, 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout); break;
+        case 3: hipLaunchKernelGGL(layernorm_fwd_kernel<3>, grid, blk, 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout); break;
+        default: hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, blk, 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout); break;
     }
 }
 void k_layernorm_bwd(const bf16* dh, const float* x, const float* mean, const float* rstd, const float* g,
@@ -465,8 +479,10 @@ void k_head_fwd(const float* x, int B, int T, int D, int C, float eps, const flo
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), (D + 4) * sizeof(float), s, x, T, D, C, eps, g, b, Wc, bc,
                        xhat, xf, rstd, logits);
 }
-void k_ce_loss(const float* logits, const int64_t* labels, int B, int C, float* dlogits, float* loss, hipStream_t s) {
-    hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(256), 0, s, logits, labels, B, C, dlogits, loss);
+void k_ce_loss(const float* logits, const int64_t* labels, int B, int C, float* dlogits, float* loss_img, float* loss,
+               hipStream_t s) {
+    hipLaunchKernelGGL(ce_loss_kernel, dim3((B + 3) / 4), dim3(256), 0, s, logits, labels, B, C, dlogits, loss_img);
+    hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, s, loss_img, B, loss);
 }
 void k_head_bwd(const float* dlogits, const float* Wc, const float* g, const float* xhat, const float* rstd, int B,
                 int T, int D, int C, float* dx, bf16* dx_bf, hipStream_t s) {

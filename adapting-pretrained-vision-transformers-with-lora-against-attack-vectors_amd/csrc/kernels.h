@@ -7,13 +7,16 @@
 void k_patch_gather(const float* x, bf16* out, int B, int S, int P, int normalise, const float* mean,
                     const float* std, hipStream_t s);
 void k_cls_rows(float* x, const float* cls, const float* pos, int B, int T, int D, hipStream_t s);
+// h = LN(x) (bf16) + row statistics.  With `delta`: first x_out = x + delta (fp32 residual stream + the bf16
+// output of the projection before it), then the LN of x_out; h == nullptr: the add alone.
 void k_layernorm_fwd(const float* x, bf16* h, float* mean, float* rstd, const float* g, const float* b, int M, int D,
-                     float eps, hipStream_t s);
+                     float eps, const bf16* delta, float* xout, hipStream_t s);
 void k_layernorm_bwd(const bf16* dh, const float* x, const float* mean, const float* rstd, const float* g,
                      const float* dres, float* dx, bf16* dx_bf, int M, int D, hipStream_t s);
 void k_head_fwd(const float* x, int B, int T, int D, int C, float eps, const float* g, const float* b, const float* Wc,
                 const float* bc, float* xhat, float* xf, float* rstd, float* logits, hipStream_t s);
-void k_ce_loss(const float* logits, const int64_t* labels, int B, int C, float* dlogits, float* loss, hipStream_t s);
+void k_ce_loss(const float* logits, const int64_t* labels, int B, int C, float* dlogits, float* loss_img, float* loss,
+               hipStream_t s);
 void k_head_bwd(const float* dlogits, const float* Wc, const float* g, const float* xhat, const float* rstd, int B,
                 int T, int D, int C, float* dx, bf16* dx_bf, hipStream_t s);
 void k_classifier_grad(const float* dlogits, const float* xf, int B, int D, int C, float* dW, float* db, hipStream_t s);

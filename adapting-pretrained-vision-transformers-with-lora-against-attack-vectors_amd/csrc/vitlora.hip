@@ -78,7 +78,7 @@ struct Workspace {
     std::vector<bf16*> qkv, ctx, z;
     std::vector<float*> lse;
     std::vector<bf16*> t[4];         // LoRA down outputs (per layer in train mode)
-    float *xhat, *xf, *rstd_f, *logits, *dlogits, *loss;
+    float *xhat, *xf, *rstd_f, *logits, *dlogits, *loss, *loss_img;
     float* dres[2];
     bf16 *dres_bf, *dh, *dctx, *dqkv, *dz, *u;
     bf16* xd;                        // train mode: dropout(x) of the current LoRA branch / dgrad temporary [Mpad, MLP]
@@ -109,6 +109,7 @@ struct vl_model {
     hipStream_t cap_stream = nullptr;
     struct { const void* x0; const void* labels; void* adv; int B; float eps, alpha; } gkey = {};
     int use_graph = 1;
+    int resid_epi = 0;    // VITLORA_RESID=epilogue: residual add in the o / fc2 GEMM epilogue (fp32 read-modify-write), for A/B runs
     int attn16 = 0;       // VITLORA_ATTN16=1: first-generation (16x16x32) attention kernels, for A/B runs
     int plan_batch = 0, plan_train = 0;
     float mean[3] = {0.485f, 0.456f, 0.406f};   // get_normalization, Utils.py:92-93
@@ -243,6 +244,7 @@ int vl_create(const vl_config* cfg, vl_model** out) {
     m->use_graph = !(ng && ng[0] == '1');
     const char* a16 = getenv("VITLORA_ATTN16");
     m->attn16 = (a16 && a16[0] == '1') ? 1 : 0;
+    { const char* re = getenv("VITLORA_RESID"); m->resid_epi = (re && !strcmp(re, "epilogue")) ? 1 : 0; }
     const int D = m->D, MLP = m->MLP, r = m->r;
     int rc;
 #define A_(p, n) if ((rc = dev_alloc(m, &(p), (size_t)(n))) != VL_OK) { vl_destroy(m); return rc; }
@@ -469,6 +471,7 @@ static size_t carve(vl_model* m, int B, int train, char* base) {
     w.rstd_f = (float*)take((size_t)B * 4);
     w.logits = (float*)take((size_t)B * m->C * 4); w.dlogits = (float*)take((size_t)B * m->C * 4);
     w.loss = (float*)take(256);
+    w.loss_img = (float*)take((size_t)B * 4);
     w.dres[0] = (float*)take((size_t)Mpad * D * 4); w.dres[1] = (float*)take((size_t)Mpad * D * 4);
     w.dres_bf = (bf16*)take((size_t)Mpad * D * 2);
     w.dh = (bf16*)take((size_t)Mpad * D * 2);
@@ -526,22 +529,31 @@ static int forward_impl(vl_model* m, const float* x, int B, int normalise, int t
         launch_gemm(g, EPI_PATCH_FWD, 128, s);
     }
     k_cls_rows(w.xs[0], m->cls, m->pos, B, T, D, s);
+    // residual stream: the o / fc2 projections store their output (bias and LoRA included) as bf16 and the
+    // LayerNorm that follows adds it to the fp32 stream while it normalises (one pass over x instead of a
+    // 4 + 4 B/element read-modify-write in the GEMM epilogue, which the MFMA loop cannot hide)
+    bf16* delta = w.dres_bf;                         // backward scratch, idle during the forward
+    const bool re = m->resid_epi;
     for (int l = 0; l < L; ++l) {
         Layer& ly = m->layers[l];
         GemmArgs g;
-        k_layernorm_fwd(w.xs[2 * l], w.h1[l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, ly.ln1_b, M, D, m->cfg.ln_eps, s);
+        if (l == 0 || re) k_layernorm_fwd(w.xs[2 * l], w.h1[l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, ly.ln1_b, M, D, m->cfg.ln_eps, nullptr, nullptr, s);
+        else k_layernorm_fwd(w.xs[2 * l - 1], w.h1[l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, ly.ln1_b, M, D, m->cfg.ln_eps, delta, w.xs[2 * l], s);
         memset(&g, 0, sizeof g); g.C = w.qkv[l]; g.ldc = 3 * D;
         linear_fwd(m, ly.lin[LQKV], w.h1[l], w.t[LQKV][l], Mpad, g, EPI_STORE_BF16, s, l * 4 + LQKV);
         if ((m->attn16 ? k_attention_fwd : k_attention32_fwd)(w.qkv[l], w.ctx[l], w.lse[l], B, T, m->H, D, s)) return fail(VL_ERR_UNSUPPORTED, "attention: T > 224");
-        memset(&g, 0, sizeof g); g.C = w.xs[2 * l + 1]; g.ldc = D; g.R = w.xs[2 * l]; g.ldr = D;
-        linear_fwd(m, ly.lin[LO], w.ctx[l], w.t[LO][l], Mpad, g, EPI_RESID_F32, s, l * 4 + LO);
-        k_layernorm_fwd(w.xs[2 * l + 1], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D,
-                        m->cfg.ln_eps, s);
+        memset(&g, 0, sizeof g); g.C = delta; g.ldc = D;
+        if (re) { g.C = w.xs[2 * l + 1]; g.R = w.xs[2 * l]; g.ldr = D; }
+        linear_fwd(m, ly.lin[LO], w.ctx[l], w.t[LO][l], Mpad, g, re ? EPI_RESID_F32 : EPI_STORE_BF16, s, l * 4 + LO);
+        if (re) k_layernorm_fwd(w.xs[2 * l + 1], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D, m->cfg.ln_eps, nullptr, nullptr, s);
+        else k_layernorm_fwd(w.xs[2 * l], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D, m->cfg.ln_eps, delta, w.xs[2 * l + 1], s);
         memset(&g, 0, sizeof g); g.C = w.a[l]; g.ldc = m->MLP; g.C2 = w.z[l]; g.ldc2 = m->MLP;
         linear_fwd(m, ly.lin[LFC1], w.h2[l], w.t[LFC1][l], Mpad, g, EPI_GELU, s, l * 4 + LFC1);
-        memset(&g, 0, sizeof g); g.C = w.xs[2 * l + 2]; g.ldc = D; g.R = w.xs[2 * l + 1]; g.ldr = D;
-        linear_fwd(m, ly.lin[LFC2], w.a[l], w.t[LFC2][l], Mpad, g, EPI_RESID_F32, s, l * 4 + LFC2);
+        memset(&g, 0, sizeof g); g.C = delta; g.ldc = D;
+        if (re) { g.C = w.xs[2 * l + 2]; g.R = w.xs[2 * l + 1]; g.ldr = D; }
+        linear_fwd(m, ly.lin[LFC2], w.a[l], w.t[LFC2][l], Mpad, g, re ? EPI_RESID_F32 : EPI_STORE_BF16, s, l * 4 + LFC2);
     }
+    if (!re) k_layernorm_fwd(w.xs[2 * L - 1], nullptr, nullptr, nullptr, nullptr, nullptr, M, D, m->cfg.ln_eps, delta, w.xs[2 * L], s);
     k_head_fwd(w.xs[2 * L], B, T, D, m->C, m->cfg.ln_eps, m->lnf_g, m->lnf_b, m->flat + m->cls_w_off,
                m->flat + m->cls_b_off, w.xhat, w.xf, w.rstd_f, w.logits, s);
     m->cur_B = B; m->cur_norm = normalise; m->cur_train = train; m->have_loss = 0;
@@ -563,7 +575,7 @@ int vl_loss_ce(vl_model* m, const int64_t* labels, float* loss_out, void* stream
     if (!m || !labels) return fail(VL_ERR_ARG, "null argument");
     if (!m->cur_B) return fail(VL_ERR_STATE, "vl_loss_ce before vl_forward");
     hipStream_t s = (hipStream_t)stream;
-    k_ce_loss(m->ws.logits, labels, m->cur_B, m->C, m->ws.dlogits, m->ws.loss, s);
+    k_ce_loss(m->ws.logits, labels, m->cur_B, m->C, m->ws.dlogits, m->ws.loss_img, m->ws.loss, s);
     if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, m->ws.loss, sizeof(float), hipMemcpyDeviceToDevice, s));
     m->have_loss = 1;
     return VL_OK;
@@ -717,7 +729,7 @@ static int pgd_iteration(vl_model* m, const float* x0, const int64_t* labels, in
                          hipStream_t s) {
     int rc = forward_impl(m, adv, B, 1, 0, s);
     if (rc) return rc;
-    k_ce_loss(m->ws.logits, labels, B, m->C, m->ws.dlogits, m->ws.loss, s);
+    k_ce_loss(m->ws.logits, labels, B, m->C, m->ws.dlogits, m->ws.loss_img, m->ws.loss, s);
     m->have_loss = 1;
     rc = backward_impl(m, m->ws.grad_img, nullptr, s);
     if (rc) return rc;

@@ -278,13 +278,13 @@ def vit_forward(w: Dict[str, torch.Tensor], cfg: OracleConfig, x_norm: torch.Ten
         if trace is not None:
             trace[f"qkv{i}"] = torch.cat([t_.transpose(1, 2).reshape(B, N, D) for t_ in (q, k_, v)], dim=-1).detach()
             trace[f"ctx{i}"] = ctx.detach()
-        x = x + lin("o", ctx)
+        x = x + _rb(lin("o", ctx), sim)       # projection output held as bf16, added by the next LN pass
         if trace is not None:
             trace[f"xs{2 * i + 1}"] = x.detach()
         h2 = _rb(F.layer_norm(x, (D,), w[p + "layernorm_after.weight"],
                               w[p + "layernorm_after.bias"], cfg.ln_eps), sim)
         a = _rb(F.gelu(lin("fc1", h2)), sim)          # exact erf GELU (hidden_act="gelu")
-        x = x + lin("fc2", a)
+        x = x + _rb(lin("fc2", a), sim)
         if trace is not None:
             trace[f"xs{2 * i + 2}"] = x.detach()
     xf = F.layer_norm(x[:, 0], (D,), w["vit.layernorm.weight"], w["vit.layernorm.bias"], cfg.ln_eps)

@@ -26,6 +26,13 @@ __global__ __launch_bounds__(512) void k(char* out, int ld_bytes, int tiles_per_
                 char* r = base + (size_t)(wm * 128 + i * 16 + fr) * ld_bytes + wn * 128 + fg * 16;
                 *(f32x4*)r = v; *(f32x4*)(r + 64) = v;
             }
+        } else if (MODE == 3) {
+            // per-wave 128 x 64 sub-tile written as full 128 B lines: a wave instruction = 8 rows x 128 B
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                char* r = base + (size_t)(wm * 128 + i * 8 + (lane >> 3)) * ld_bytes + wn * 128 + (lane & 7) * 16;
+                *(f32x4*)r = v;
+            }
         } else {
             // coalesced: a wave instruction writes 2 rows x 512 B
 #pragma unroll
@@ -42,13 +49,14 @@ int main(int argc, char** argv) {
     const int M = 50432, N = 3072, tilesN = N / 256, ntiles = (M / 256) * tilesN;
     char* out; hipMalloc(&out, (size_t)M * N * 2);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
         float best = 1e9;
         for (int rep = 0; rep < 5; ++rep) {
             hipEventRecord(e0);
             if (mode == 0) k<0><<<G, 512>>>(out, N * 2, 9, tilesN);
             if (mode == 1) k<1><<<G, 512>>>(out, N * 2, 9, tilesN);
             if (mode == 2) k<2><<<G, 512>>>(out, N * 2, 9, tilesN);
+            if (mode == 3) k<3><<<G, 512>>>(out, N * 2, 9, tilesN);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
         }
