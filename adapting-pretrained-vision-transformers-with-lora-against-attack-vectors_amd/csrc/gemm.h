@@ -35,6 +35,8 @@ struct GemmArgs {
     int a_gather;
     // algorithmic sizes for profiling (0 = use N / K2): true LoRA rank columns, not the padded ones
     int n_algo, k2_algo;
+    int k2_used;          // nonzero columns of the LoRA K tile (r * modules); <= 32 lets the 256-row kernel skip its upper half
+
     int dephase;      // gemm256: start offset unit (x 8128 cycles x (workgroup/8 mod 4)); 0 = off
     // EPI_DROP_ACC: dropout mask of element (m, n) of the module input = drop_scale(seed, stream, m*N + n)
     const bf16* G; int ldg;          // optional extra factor (gelu'(z) for the fc2 input gradient)

@@ -174,17 +174,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
                 wf[nh][1][j] = *(const bf16x8*)(r + xo1);
             }
         };
-        auto mma = [&](int mh, int nh) {
+        // lower_only: the K tile's upper 32 columns are zero on both sides (LoRA tile with r * modules <= 32)
+        auto mma = [&](int mh, int nh, bool lower_only) {
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks == 1 && lower_only) break;
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[mh * MI + i][nh * 2 + j] = mfma16(wf[nh][ks][j], af[ks][i], acc[mh * MI + i][nh * 2 + j]);
+            }
             __builtin_amdgcn_s_setprio(0);
         };
+        const bool ext_half = p.K2 == BK && p.k2_used > 0 && p.k2_used <= 32;   // the LoRA tile is the last K tile
         // MODE 0: steady state (K tiles T+1 and T+2 exist); 1: T = nk-2; 2: T = nk-1
         // EXC: older in-flight epilogue instructions to tolerate (K tile 0 only)
         auto ktile = [&](int T, auto mode, auto extra) {
@@ -196,25 +200,25 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
             readW(buf, 0);
             if constexpr (MODE <= 1) { issueW(bn, 1, T + 1); VMCNT(clamp63(STEADY + EXC)); } else { VMCNT(NA); }
             BARRIER();
-            mma(0, 0);
+            mma(0, 0, MODE == 2 && ext_half);
             BARRIER();
             // P2
             readW(buf, 1);
             if constexpr (MODE <= 1) { issueA(bm, 1, T + 1); VMCNT(clamp63(STEADY + EXC)); } else { VMCNT(0); }
             BARRIER();
-            mma(0, 1);
+            mma(0, 1, MODE == 2 && ext_half);
             BARRIER();
             // P3
             readA(buf, 1);
             if constexpr (MODE == 0) issueA(bm, 0, T + 2);
             BARRIER();
-            mma(1, 1);
+            mma(1, 1, MODE == 2 && ext_half);
             BARRIER();
             // P4
             if constexpr (MODE == 0) { issueW(bn, 0, T + 2); VMCNT(clamp63(STEADY + EXC)); }
             if constexpr (MODE == 1) { VMCNT(clamp63(NA + NW + EXC)); }
             BARRIER();
-            mma(1, 0);
+            mma(1, 0, MODE == 2 && ext_half);
             BARRIER();
         };
 

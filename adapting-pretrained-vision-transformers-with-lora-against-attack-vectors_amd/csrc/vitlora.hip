@@ -158,6 +158,7 @@ void linear_fwd(vl_model* m, const Linear& ln, const bf16* x, bf16* t, int Mpad,
         GemmArgs d = gemm_args(xb, ln.in, ln.Ad, ln.in, ln.in, Mpad, ln.kext);
         d.Mvalid = m->cur_M; d.n_algo = m->r * (int)ln.slots.size();
         g.k2_algo = m->r;      // each output column sees r LoRA columns
+        g.k2_used = m->r * (int)ln.slots.size();
         d.C = t; d.ldc = ln.kext;
         launch_gemm(d, EPI_STORE_BF16, 64, s);
         add_ext(g, t, ln.kext, ln.Bu, ln.kext, ln.kext);
@@ -193,6 +194,7 @@ void linear_dgrad(vl_model* m, const Linear& ln, const bf16* dy, bf16* u, int Mp
             return;
         }
         g.k2_algo = m->r * (int)ln.slots.size();
+        g.k2_used = g.k2_algo;
         add_ext(g, u, ln.kext, ln.Au, ln.kext, ln.kext);
     }
     launch_gemm(g, epi, 128, s);
