@@ -101,18 +101,82 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     }
 }
 
+// LoRA down-projection of ONE row fused into the kernel that produces the row (saves the separate skinny GEMM's
+// pass over the activation): out[j] = sum_c v[c] * P[j][c] for the 8*NG rows of P (bf16 [>= 8*NG, D], zero rows
+// past r * modules), written as a full 64-column bf16 row (zeros past 8*NG).  v = this lane's 4*NV values of the
+// row (the bf16 values the GEMM this replaces would read), columns (lane + 64 i)*4 + k.
+// Reduction: halving butterfly (4 + 2 + 1 exchanges leave lane L with column (L>>3)&7) + 3 xor steps.
+template <int NV, int NG>
+struct LoraDownP { bf16x4 p[NG][NV][8]; };
+// this lane's slice of P, fetched EARLY (before the row's own loads are consumed) so that its L2 latency hides
+template <int NV, int NG>
+__device__ __forceinline__ void lora_down_load(LoraDownP<NV, NG>& r, int nv, int lane, const bf16* __restrict__ P, int D) {
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                r.p[gq][i][j] = c < nv ? *(const bf16x4*)(P + (size_t)(gq * 8 + j) * D + c * 4) : bf16x4{0, 0, 0, 0};
+        }
+}
+template <int NV, int NG>
+__device__ __forceinline__ void lora_down_row(const bf16x4 (&v)[NV], const LoraDownP<NV, NG>& r, int nv, int lane,
+                                              bf16* __restrict__ out_row) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    float outv = 0.f;
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+                const bf2 vlo = {v[i][0], v[i][1]}, vhi = {v[i][2], v[i][3]};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bf16x4 p = r.p[gq][i][j];
+                    const bf2 plo = {p[0], p[1]}, phi = {p[2], p[3]};
+                    acc[j] = __builtin_amdgcn_fdot2_f32_bf16(vlo, plo, acc[j], false);     // v_dot2c_f32_bf16: no conversions
+                    acc[j] = __builtin_amdgcn_fdot2_f32_bf16(vhi, phi, acc[j], false);
+                }
+            }
+        }
+        const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+        float a4[4], a2[2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a4[q] = (b5 ? acc[4 + q] : acc[q]) + __shfl_xor(b5 ? acc[q] : acc[4 + q], 32, 64);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a2[q] = (b4 ? a4[2 + q] : a4[q]) + __shfl_xor(b4 ? a4[q] : a4[2 + q], 16, 64);
+        float a1 = (b3 ? a2[1] : a2[0]) + __shfl_xor(b3 ? a2[0] : a2[1], 8, 64);
+        a1 += __shfl_xor(a1, 4, 64);
+        a1 += __shfl_xor(a1, 2, 64);
+        a1 += __shfl_xor(a1, 1, 64);
+        const float routed = __shfl(a1, (lane & 7) << 3, 64);       // column j sits in lanes 8j .. 8j+7
+        if ((lane >> 3) == gq) outv = routed;
+    }
+    out_row[lane] = f2bf(lane < 8 * NG ? outv : 0.f);
+}
+
 // LayerNorm backward fused with the residual-gradient add:
 //   dx = dres + rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dh * gamma
 // writes dx as f32 (residual-gradient stream) and as bf16 (A operand of the next dgrad GEMM).
-template <int NV>
+template <int NV, int NG>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restrict__ dh, const float* __restrict__ x,
                                                             const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                             const float* __restrict__ gamma, const float* __restrict__ dres,
-                                                            float* __restrict__ dx, bf16* __restrict__ dx_bf, int M, int D) {
+                                                            float* __restrict__ dx, bf16* __restrict__ dx_bf, int M, int D,
+                                                            const bf16* __restrict__ P, bf16* __restrict__ u) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
     const int nv = D >> 2;
+    // with the fused projection a wave keeps its slice of P in registers and walks rows (grid-stride): P is read
+    // once per wave, not once per row (per row it would double the kernel's L1 requests)
+    LoraDownP<NV, NG ? NG : 1> pr;
+    if constexpr (NG > 0) lora_down_load<NV, NG>(pr, nv, lane, P, D);
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
     const float mean = mean_in[row], rstd = rstd_in[row];
     const int64_t off = (int64_t)row * D;
     f32x4 g[NV], xh[NV];
@@ -136,6 +200,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
         }
     }
     const float c1 = wave_sum(s1) / D, c2 = wave_sum(s2) / D;
+    bf16x4 vb[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
@@ -149,7 +214,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
             }
             *(f32x4*)(dx + off + c * 4) = o;
             *(bf16x4*)(dx_bf + off + c * 4) = ob;
+            vb[i] = ob;                                              // the row as the next dgrad GEMM reads it
         }
+    }
+    // u = dx_bf B of the projection whose dgrad consumes dx_bf next (linear_dgrad skips its down GEMM)
+    if constexpr (NG > 0) lora_down_row<NV, NG>(vb, pr, nv, lane, u + (int64_t)row * 64);
     }
 }
 
@@ -461,16 +530,25 @@ void k_layernorm_fwd(const float* x, bf16* h, float* mean, float* rstd, const fl
         default: hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, blk, 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout); break;
     }
 }
+template <int NV>
+static void launch_ln_bwd(dim3 grid, hipStream_t s, const bf16* dh, const float* x, const float* mean, const float* rstd,
+                          const float* g, const float* dres, float* dx, bf16* dx_bf, int M, int D, const bf16* P, int ng, bf16* u) {
+    if (ng == 1) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 1>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D, P, u);
+    else if (ng == 2) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 2>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D, P, u);
+    else hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 0>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D, P, u);
+}
 void k_layernorm_bwd(const bf16* dh, const float* x, const float* mean, const float* rstd, const float* g,
-                     const float* dres, float* dx, bf16* dx_bf, int M, int D, hipStream_t s) {
+                     const float* dres, float* dx, bf16* dx_bf, int M, int D, const bf16* P, int ng, bf16* u, hipStream_t s) {
     ProfScope prof_("layernorm_bwd_kernel", 0.0, (double)M * D * 16.0, s);
     const int nv = (D / 4 + 63) / 64;
-    dim3 grid((M + 3) / 4), blk(256);
+    if (!P || !u || ng < 0 || ng > 2) ng = 0;
+    dim3 grid((M + 3) / 4);
+    if (ng && grid.x > 1024) grid.x = 1024;          // 4 resident blocks per CU walk the rows
     switch (nv) {
-        case 1: hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, blk, 0, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D); break;
-        case 2: hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, blk, 0, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D); break;
-        case 3: hipLaunchKernelGGL(layernorm_bwd_kernel<3>, grid, blk, 0, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D); break;
-        default: hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, blk, 0, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D); break;
+        case 1: launch_ln_bwd<1>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D, P, ng, u); break;
+        case 2: launch_ln_bwd<2>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D, P, ng, u); break;
+        case 3: launch_ln_bwd<3>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D, P, ng, u); break;
+        default: launch_ln_bwd<4>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D, P, ng, u); break;
     }
 }
 void k_head_fwd(const float* x, int B, int T, int D, int C, float eps, const float* g, const float* b, const float* Wc,

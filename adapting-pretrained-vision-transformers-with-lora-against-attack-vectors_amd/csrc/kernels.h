@@ -11,8 +11,10 @@ void k_cls_rows(float* x, const float* cls, const float* pos, int B, int T, int 
 // output of the projection before it), then the LN of x_out; h == nullptr: the add alone.
 void k_layernorm_fwd(const float* x, bf16* h, float* mean, float* rstd, const float* g, const float* b, int M, int D,
                      float eps, const bf16* delta, float* xout, hipStream_t s);
+// P / ng / u: optional fused LoRA down-projection of the bf16 output row (u[row][0..63] = dx_bf[row] . P[j], 8*ng rows
+// of P [>= 8*ng, D]; ng in {1, 2}; u has 64 columns), see lora_down_row in elementwise.hip
 void k_layernorm_bwd(const bf16* dh, const float* x, const float* mean, const float* rstd, const float* g,
-                     const float* dres, float* dx, bf16* dx_bf, int M, int D, hipStream_t s);
+                     const float* dres, float* dx, bf16* dx_bf, int M, int D, const bf16* P, int ng, bf16* u, hipStream_t s);
 void k_head_fwd(const float* x, int B, int T, int D, int C, float eps, const float* g, const float* b, const float* Wc,
                 const float* bc, float* xhat, float* xf, float* rstd, float* logits, hipStream_t s);
 void k_ce_loss(const float* logits, const int64_t* labels, int B, int C, float* dlogits, float* loss_img, float* loss,

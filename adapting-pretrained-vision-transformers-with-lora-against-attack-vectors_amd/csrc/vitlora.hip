@@ -140,6 +140,14 @@ void add_ext(GemmArgs& g, const bf16* A2, int lda2, const bf16* W2, int ldw2, in
     g.A2 = A2; g.lda2 = lda2; g.W2 = W2; g.ldw2 = ldw2; g.K2 = K2;
 }
 
+// 8-row groups of Bd the LayerNorm-backward kernel can project its output row onto (0: not fusable, the
+// skinny GEMM runs): a 64-column u, r * modules <= 16, dy as wide as the residual stream.
+int fused_down(const vl_model* m, const Linear& ln) {
+    if (m->cfg.lora_merged || !ln.kext || ln.slots.empty() || ln.kext != 64 || ln.out != m->D) return 0;
+    const int nc = m->r * (int)ln.slots.size();
+    return nc <= 8 ? 1 : nc <= 16 ? 2 : 0;
+}
+
 bool drop_on(const vl_model* m) { return m->cur_train && m->r && m->cfg.lora_dropout > 0.f; }
 
 // y = x W^T (+ LoRA) with epilogue; `t` receives the LoRA down projection when fused.
@@ -167,8 +175,9 @@ void linear_fwd(vl_model* m, const Linear& ln, const bf16* x, bf16* t, int Mpad,
 }
 
 // dx = dy W (+ LoRA) with epilogue; `u` receives dy B.
+// u_ready: the kernel that produced dy already wrote u (fused_down below).
 void linear_dgrad(vl_model* m, const Linear& ln, const bf16* dy, bf16* u, int Mpad, GemmArgs g, int epi, hipStream_t s,
-                  uint32_t stream_id) {
+                  uint32_t stream_id, bool u_ready = false) {
     g.A1 = dy; g.lda1 = ln.out; g.W1 = ln.WT; g.ldw1 = ln.out; g.K1 = ln.out;
     g.M = Mpad; g.N = ln.in; g.bias = nullptr;
     g.Mvalid = m->cur_M;
@@ -177,7 +186,7 @@ void linear_dgrad(vl_model* m, const Linear& ln, const bf16* dy, bf16* u, int Mp
         // u = dy B: each of the r*slots columns sums over its own module's `out` rows only
         d.Mvalid = m->cur_M; d.n_algo = m->r; 
         d.C = u; d.ldc = ln.kext;
-        launch_gemm(d, EPI_STORE_BF16, 64, s);
+        if (!u_ready) launch_gemm(d, EPI_STORE_BF16, 64, s);
         if (drop_on(m)) {
             // the LoRA branch saw dropout(x): d(x) = dy W + mask * (u (sA)), then the caller's epilogue factor.
             // two launches: the frozen part into a temporary, then the masked rank-r part on top of it.
@@ -624,25 +633,28 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
         GemmArgs g;
         // MLP: dz = (dx2 Wfc2 (+LoRA)) * gelu'(z)
         memset(&g, 0, sizeof g); g.C = w.dz; g.ldc = MLP; g.R = w.z[l]; g.ldr = MLP;
-        linear_dgrad(m, ly.lin[LFC2], w.dres_bf, w.u, Mpad, g, EPI_GELU_BWD, s, l * 4 + LFC2);
+        // u of this dgrad came with dres_bf from the LayerNorm backward of the layer above (not for the top layer)
+        linear_dgrad(m, ly.lin[LFC2], w.dres_bf, w.u, Mpad, g, EPI_GELU_BWD, s, l * 4 + LFC2, l < L - 1 && fused_down(m, ly.lin[LFC2]) > 0);
         wgrad(ly.lin[LFC2], w.dres_bf, w.a[l], w.t[LFC2][l], w.u, l * 4 + LFC2);
         memset(&g, 0, sizeof g); g.C = w.dh; g.ldc = D;
         linear_dgrad(m, ly.lin[LFC1], w.dz, w.u, Mpad, g, EPI_STORE_BF16, s, l * 4 + LFC1);
         wgrad(ly.lin[LFC1], w.dz, w.h2[l], w.t[LFC1][l], w.u, l * 4 + LFC1);
+        const int fo = fused_down(m, ly.lin[LO]);
         k_layernorm_bwd(w.dh, w.xs[2 * l + 1], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, w.dres[cur], w.dres[cur ^ 1],
-                        w.dres_bf, M, D, s);
+                        w.dres_bf, M, D, ly.lin[LO].Bd, fo, w.u, s);
         cur ^= 1;
         // attention block
         memset(&g, 0, sizeof g); g.C = w.dctx; g.ldc = D;
-        linear_dgrad(m, ly.lin[LO], w.dres_bf, w.u, Mpad, g, EPI_STORE_BF16, s, l * 4 + LO);
+        linear_dgrad(m, ly.lin[LO], w.dres_bf, w.u, Mpad, g, EPI_STORE_BF16, s, l * 4 + LO, fo > 0);
         wgrad(ly.lin[LO], w.dres_bf, w.ctx[l], w.t[LO][l], w.u, l * 4 + LO);
         if ((m->attn16 ? k_attention_bwd : k_attention32_bwd)(w.qkv[l], w.ctx[l], w.dctx, w.lse[l], w.dqkv, B, T, m->H, D, s))
             return fail(VL_ERR_UNSUPPORTED, "attention: T > 224");
         memset(&g, 0, sizeof g); g.C = w.dh; g.ldc = D;
         linear_dgrad(m, ly.lin[LQKV], w.dqkv, w.u, Mpad, g, EPI_STORE_BF16, s, l * 4 + LQKV);
         wgrad(ly.lin[LQKV], w.dqkv, w.h1[l], w.t[LQKV][l], w.u, l * 4 + LQKV);
+        const int ff = l > 0 ? fused_down(m, m->layers[l - 1].lin[LFC2]) : 0;     // next consumer: fc2 dgrad of the layer below
         k_layernorm_bwd(w.dh, w.xs[2 * l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, w.dres[cur], w.dres[cur ^ 1], w.dres_bf,
-                        M, D, s);
+                        M, D, ff ? m->layers[l - 1].lin[LFC2].Bd : nullptr, ff, w.u, s);
         cur ^= 1;
     }
     if (grad_x) {
