@@ -48,59 +48,6 @@ __global__ void cls_rows_kernel(float* __restrict__ x, const float* __restrict__
 // ---------------------------------------------------------------------------------
 // LayerNorm forward: one wave per row, two-pass statistics in registers.
 // ---------------------------------------------------------------------------------
-template <int NV>
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, bf16* __restrict__ h,
-                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            int M, int D, float eps, const bf16* __restrict__ delta,
-                                                            float* __restrict__ xout) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const int nv = D >> 2;
-    const float* xr = x + (int64_t)row * D;
-    f32x4 v[NV];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = lane + i * 64;
-        v[i] = c < nv ? *(const f32x4*)(xr + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (delta && c < nv) {
-            // residual add fused in: x_out = x + delta (the bf16 output of the projection before it)
-            const bf16x4 dl = *(const bf16x4*)(delta + (int64_t)row * D + c * 4);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[i][k] += bf2f(dl[k]);
-            *(f32x4*)(xout + (int64_t)row * D + c * 4) = v[i];
-        }
-        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-    }
-    if (!h) return;                                  // add only (last layer: the head normalises the CLS rows)
-    const float mean = wave_sum(s) / D;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = lane + i * 64;
-        if (c < nv) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { const float d = v[i][k] - mean; q += d * d; }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / D + eps);
-    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
-    bf16* hr = h + (int64_t)row * D;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = lane + i * 64;
-        if (c < nv) {
-            const f32x4 g = *(const f32x4*)(gamma + c * 4), b = *(const f32x4*)(beta + c * 4);
-            bf16x4 o;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = f2bf((v[i][k] - mean) * rstd * g[k] + b[k]);
-            *(bf16x4*)(hr + c * 4) = o;
-        }
-    }
-}
-
 // LoRA down-projection of ONE row fused into the kernel that produces the row (saves the separate skinny GEMM's
 // pass over the activation): out[j] = sum_c v[c] * P[j][c] for the 8*NG rows of P (bf16 [>= 8*NG, D], zero rows
 // past r * modules), written as a full 64-column bf16 row (zeros past 8*NG).  v = this lane's 4*NV values of the
@@ -159,6 +106,65 @@ __device__ __forceinline__ void lora_down_row(const bf16x4 (&v)[NV], const LoraD
         if ((lane >> 3) == gq) outv = routed;
     }
     out_row[lane] = f2bf(lane < 8 * NG ? outv : 0.f);
+}
+
+template <int NV, int NG>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, bf16* __restrict__ h,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            int M, int D, float eps, const bf16* __restrict__ delta,
+                                                            float* __restrict__ xout, const bf16* __restrict__ P,
+                                                            bf16* __restrict__ t) {
+    const int lane = threadIdx.x & 63;
+    const int nv = D >> 2;
+    LoraDownP<NV, NG ? NG : 1> pr;                  // fused t = h Ad^T of the projection that reads h next (see layernorm_bwd_kernel)
+    if constexpr (NG > 0) lora_down_load<NV, NG>(pr, nv, lane, P, D);
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+        const float* xr = x + (int64_t)row * D;
+        f32x4 v[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            v[i] = c < nv ? *(const f32x4*)(xr + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (delta && c < nv) {
+                // residual add fused in: x_out = x + delta (the bf16 output of the projection before it)
+                const bf16x4 dl = *(const bf16x4*)(delta + (int64_t)row * D + c * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[i][k] += bf2f(dl[k]);
+                *(f32x4*)(xout + (int64_t)row * D + c * 4) = v[i];
+            }
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+        if (!h) continue;                            // add only (last layer: the head normalises the CLS rows)
+        const float mean = wave_sum(s) / D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float d = v[i][k] - mean; q += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / D + eps);
+        if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+        bf16* hr = h + (int64_t)row * D;
+        bf16x4 vb[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+                const f32x4 g = *(const f32x4*)(gamma + c * 4), b = *(const f32x4*)(beta + c * 4);
+                bf16x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = f2bf((v[i][k] - mean) * rstd * g[k] + b[k]);
+                *(bf16x4*)(hr + c * 4) = o;
+                vb[i] = o;
+            }
+        }
+        if constexpr (NG > 0) lora_down_row<NV, NG>(vb, pr, nv, lane, t + (int64_t)row * 64);
+    }
 }
 
 // LayerNorm backward fused with the residual-gradient add:
@@ -518,16 +524,26 @@ void k_patch_gather(const float* x, bf16* out, int B, int S, int P, int normalis
 void k_cls_rows(float* x, const float* cls, const float* pos, int B, int T, int D, hipStream_t s) {
     hipLaunchKernelGGL(cls_rows_kernel, dim3(nblk((int64_t)B * D, 256)), dim3(256), 0, s, x, cls, pos, B, T, D);
 }
+template <int NV>
+static void launch_ln_fwd(dim3 grid, hipStream_t s, const float* x, bf16* h, float* mean, float* rstd, const float* g,
+                          const float* b, int M, int D, float eps, const bf16* delta, float* xout, const bf16* P, int ng, bf16* t) {
+    if (ng == 1) hipLaunchKernelGGL((layernorm_fwd_kernel<NV, 1>), grid, dim3(256), 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, t);
+    else if (ng == 2) hipLaunchKernelGGL((layernorm_fwd_kernel<NV, 2>), grid, dim3(256), 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, t);
+    else if (ng == 3) hipLaunchKernelGGL((layernorm_fwd_kernel<NV, 3>), grid, dim3(256), 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, t);
+    else hipLaunchKernelGGL((layernorm_fwd_kernel<NV, 0>), grid, dim3(256), 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, t);
+}
 void k_layernorm_fwd(const float* x, bf16* h, float* mean, float* rstd, const float* g, const float* b, int M, int D,
-                     float eps, const bf16* delta, float* xout, hipStream_t s) {
+                     float eps, const bf16* delta, float* xout, const bf16* P, int ng, bf16* t, hipStream_t s) {
     ProfScope prof_("layernorm_fwd_kernel", 0.0, (double)M * D * (delta ? (h ? 12.0 : 10.0) : 6.0), s);
     const int nv = (D / 4 + 63) / 64;
-    dim3 grid((M + 3) / 4), blk(256);
+    if (!P || !t || !h || ng < 0 || ng > 3) ng = 0;
+    dim3 grid((M + 3) / 4);
+    if (ng && grid.x > 1024) grid.x = 1024;          // resident blocks walk the rows, P stays in registers
     switch (nv) {
-        case 1: hipLaunchKernelGGL(layernorm_fwd_kernel<1>, grid, blk, 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout); break;
-        case 2: hipLaunchKernelGGL(layernorm_fwd_kernel<2>, grid, blk, 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout); break;
-        case 3: hipLaunchKernelGGL(layernorm_fwd_kernel<3>, grid, blk, 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout); break;
-        default: hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, blk, 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout); break;
+        case 1: launch_ln_fwd<1>(grid, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, ng, t); break;
+        case 2: launch_ln_fwd<2>(grid, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, ng, t); break;
+        case 3: launch_ln_fwd<3>(grid, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, ng, t); break;
+        default: launch_ln_fwd<4>(grid, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, ng, t); break;
     }
 }
 template <int NV>

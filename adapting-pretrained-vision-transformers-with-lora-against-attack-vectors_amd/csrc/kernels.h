@@ -9,8 +9,9 @@ void k_patch_gather(const float* x, bf16* out, int B, int S, int P, int normalis
 void k_cls_rows(float* x, const float* cls, const float* pos, int B, int T, int D, hipStream_t s);
 // h = LN(x) (bf16) + row statistics.  With `delta`: first x_out = x + delta (fp32 residual stream + the bf16
 // output of the projection before it), then the LN of x_out; h == nullptr: the add alone.
+// P / ng / t: optional fused LoRA down-projection of the row of h (8*ng rows of P, ng <= 3; t has 64 columns).
 void k_layernorm_fwd(const float* x, bf16* h, float* mean, float* rstd, const float* g, const float* b, int M, int D,
-                     float eps, const bf16* delta, float* xout, hipStream_t s);
+                     float eps, const bf16* delta, float* xout, const bf16* P, int ng, bf16* t, hipStream_t s);
 // P / ng / u: optional fused LoRA down-projection of the bf16 output row (u[row][0..63] = dx_bf[row] . P[j], 8*ng rows
 // of P [>= 8*ng, D]; ng in {1, 2}; u has 64 columns), see lora_down_row in elementwise.hip
 void k_layernorm_bwd(const bf16* dh, const float* x, const float* mean, const float* rstd, const float* g,

@@ -142,18 +142,35 @@ void add_ext(GemmArgs& g, const bf16* A2, int lda2, const bf16* W2, int ldw2, in
 
 // 8-row groups of Bd the LayerNorm-backward kernel can project its output row onto (0: not fusable, the
 // skinny GEMM runs): a 64-column u, r * modules <= 16, dy as wide as the residual stream.
+// columns of the K extension in use: q, k, v keep fixed positions 0, r, 2r inside the fused qkv projection
+int ext_cols(const vl_model* m, const Linear& ln) {
+    int n = 0;
+    for (const Slot& sl : ln.slots) n = sl.ext_off + m->r > n ? sl.ext_off + m->r : n;
+    return n;
+}
 int fused_down(const vl_model* m, const Linear& ln) {
     if (m->cfg.lora_merged || !ln.kext || ln.slots.empty() || ln.kext != 64 || ln.out != m->D) return 0;
-    const int nc = m->r * (int)ln.slots.size();
+    const int nc = ext_cols(m, ln);
     return nc <= 8 ? 1 : nc <= 16 ? 2 : 0;
+}
+
+bool drop_on(const vl_model* m);
+// same for the forward: t = h Ad^T out of the LayerNorm that writes h (not with LoRA dropout: the branch then reads
+// dropout(h)).  Only r * modules <= 8 (e.g. r = 4 on q, v): with 24 columns (r = 8 on q, k, v) the 144 registers of
+// P cost the LayerNorm more (+1.1 ms per PGD iteration) than the skinny GEMM it replaces (0.3 ms) -- measured.
+int fused_down_fwd(const vl_model* m, const Linear& ln) {
+    if (m->cfg.lora_merged || !ln.kext || ln.slots.empty() || ln.kext != 64 || ln.in != m->D || drop_on(m)) return 0;
+    const int nc = ext_cols(m, ln);
+    return nc <= 8 ? 1 : 0;
 }
 
 bool drop_on(const vl_model* m) { return m->cur_train && m->r && m->cfg.lora_dropout > 0.f; }
 
 // y = x W^T (+ LoRA) with epilogue; `t` receives the LoRA down projection when fused.
 // stream_id = layer*4 + projection: names the dropout mask of this projection's LoRA branch input.
+// t_ready: the LayerNorm that produced x already wrote t (fused_down_fwd below).
 void linear_fwd(vl_model* m, const Linear& ln, const bf16* x, bf16* t, int Mpad, GemmArgs g, int epi, hipStream_t s,
-                uint32_t stream_id) {
+                uint32_t stream_id, bool t_ready = false) {
     g.A1 = x; g.lda1 = ln.in; g.W1 = ln.W; g.ldw1 = ln.in; g.K1 = ln.in;
     g.M = Mpad; g.N = ln.out; g.bias = ln.bias;
     g.Mvalid = m->cur_M;
@@ -166,9 +183,9 @@ void linear_fwd(vl_model* m, const Linear& ln, const bf16* x, bf16* t, int Mpad,
         GemmArgs d = gemm_args(xb, ln.in, ln.Ad, ln.in, ln.in, Mpad, ln.kext);
         d.Mvalid = m->cur_M; d.n_algo = m->r * (int)ln.slots.size();
         g.k2_algo = m->r;      // each output column sees r LoRA columns
-        g.k2_used = m->r * (int)ln.slots.size();
+        g.k2_used = ext_cols(m, ln);
         d.C = t; d.ldc = ln.kext;
-        launch_gemm(d, EPI_STORE_BF16, 64, s);
+        if (!t_ready) launch_gemm(d, EPI_STORE_BF16, 64, s);
         add_ext(g, t, ln.kext, ln.Bu, ln.kext, ln.kext);
     }
     launch_gemm(g, epi, 128, s);
@@ -203,7 +220,7 @@ void linear_dgrad(vl_model* m, const Linear& ln, const bf16* dy, bf16* u, int Mp
             return;
         }
         g.k2_algo = m->r * (int)ln.slots.size();
-        g.k2_used = g.k2_algo;
+        g.k2_used = ext_cols(m, ln);
         add_ext(g, u, ln.kext, ln.Au, ln.kext, ln.kext);
     }
     launch_gemm(g, epi, 128, s);
@@ -548,23 +565,25 @@ static int forward_impl(vl_model* m, const float* x, int B, int normalise, int t
     for (int l = 0; l < L; ++l) {
         Layer& ly = m->layers[l];
         GemmArgs g;
-        if (l == 0 || re) k_layernorm_fwd(w.xs[2 * l], w.h1[l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, ly.ln1_b, M, D, m->cfg.ln_eps, nullptr, nullptr, s);
-        else k_layernorm_fwd(w.xs[2 * l - 1], w.h1[l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, ly.ln1_b, M, D, m->cfg.ln_eps, delta, w.xs[2 * l], s);
+        const int n1 = fused_down_fwd(m, ly.lin[LQKV]);      // t of the qkv projection comes out of LN1
+        const bf16* P1 = n1 ? ly.lin[LQKV].Ad : nullptr;
+        if (l == 0 || re) k_layernorm_fwd(w.xs[2 * l], w.h1[l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, ly.ln1_b, M, D, m->cfg.ln_eps, nullptr, nullptr, P1, n1, w.t[LQKV][l], s);
+        else k_layernorm_fwd(w.xs[2 * l - 1], w.h1[l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, ly.ln1_b, M, D, m->cfg.ln_eps, delta, w.xs[2 * l], P1, n1, w.t[LQKV][l], s);
         memset(&g, 0, sizeof g); g.C = w.qkv[l]; g.ldc = 3 * D;
-        linear_fwd(m, ly.lin[LQKV], w.h1[l], w.t[LQKV][l], Mpad, g, EPI_STORE_BF16, s, l * 4 + LQKV);
+        linear_fwd(m, ly.lin[LQKV], w.h1[l], w.t[LQKV][l], Mpad, g, EPI_STORE_BF16, s, l * 4 + LQKV, n1 > 0);
         if ((m->attn16 ? k_attention_fwd : k_attention32_fwd)(w.qkv[l], w.ctx[l], w.lse[l], B, T, m->H, D, s)) return fail(VL_ERR_UNSUPPORTED, "attention: T > 224");
         memset(&g, 0, sizeof g); g.C = delta; g.ldc = D;
         if (re) { g.C = w.xs[2 * l + 1]; g.R = w.xs[2 * l]; g.ldr = D; }
         linear_fwd(m, ly.lin[LO], w.ctx[l], w.t[LO][l], Mpad, g, re ? EPI_RESID_F32 : EPI_STORE_BF16, s, l * 4 + LO);
-        if (re) k_layernorm_fwd(w.xs[2 * l + 1], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D, m->cfg.ln_eps, nullptr, nullptr, s);
-        else k_layernorm_fwd(w.xs[2 * l], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D, m->cfg.ln_eps, delta, w.xs[2 * l + 1], s);
+        if (re) k_layernorm_fwd(w.xs[2 * l + 1], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D, m->cfg.ln_eps, nullptr, nullptr, nullptr, 0, nullptr, s);
+        else k_layernorm_fwd(w.xs[2 * l], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D, m->cfg.ln_eps, delta, w.xs[2 * l + 1], nullptr, 0, nullptr, s);
         memset(&g, 0, sizeof g); g.C = w.a[l]; g.ldc = m->MLP; g.C2 = w.z[l]; g.ldc2 = m->MLP;
         linear_fwd(m, ly.lin[LFC1], w.h2[l], w.t[LFC1][l], Mpad, g, EPI_GELU, s, l * 4 + LFC1);
         memset(&g, 0, sizeof g); g.C = delta; g.ldc = D;
         if (re) { g.C = w.xs[2 * l + 2]; g.R = w.xs[2 * l + 1]; g.ldr = D; }
         linear_fwd(m, ly.lin[LFC2], w.a[l], w.t[LFC2][l], Mpad, g, re ? EPI_RESID_F32 : EPI_STORE_BF16, s, l * 4 + LFC2);
     }
-    if (!re) k_layernorm_fwd(w.xs[2 * L - 1], nullptr, nullptr, nullptr, nullptr, nullptr, M, D, m->cfg.ln_eps, delta, w.xs[2 * L], s);
+    if (!re) k_layernorm_fwd(w.xs[2 * L - 1], nullptr, nullptr, nullptr, nullptr, nullptr, M, D, m->cfg.ln_eps, delta, w.xs[2 * L], nullptr, 0, nullptr, s);
     k_head_fwd(w.xs[2 * L], B, T, D, m->C, m->cfg.ln_eps, m->lnf_g, m->lnf_b, m->flat + m->cls_w_off,
                m->flat + m->cls_b_off, w.xhat, w.xf, w.rstd_f, w.logits, s);
     m->cur_B = B; m->cur_norm = normalise; m->cur_train = train; m->have_loss = 0;

@@ -74,6 +74,28 @@ def test_loss_and_input_grad(image_size, batch, with_lora):
     assert agree > 0.97, agree
 
 
+@pytest.mark.parametrize("r,targets", [(4, ("q", "v")), (8, ("q",)), (16, ("q", "v")), (16, ("o", "fc2")), (32, ("q", "o", "fc2")), (8, ("fc1", "fc2"))])
+def test_lora_down_fusion_variants(r, targets):
+    """The LoRA down-projections are computed by different kernels depending on r * modules (fused into the
+    LayerNorm forward / backward rows for <= 8 / <= 16 columns, skinny GEMM otherwise): every route must agree
+    with the oracle on logits and on the input gradient."""
+    cfg, w, lora, x, y = make_case(image_size=64, batch=4, r=r, targets=targets)
+    eng = make_engine(cfg, w, lora)
+    logits = eng.forward(x.cuda(), normalise=True)
+    eng.loss_ce(y.cuda())
+    gx, _ = eng.backward(True, False, tuple(x.shape))
+    torch.cuda.synchronize()
+    _, g_sim, lg_sim = O.loss_and_input_grad(w, cfg, x, y, lora, sim_bf16=True)
+    _, g_ref, lg_ref = O.loss_and_input_grad(w, cfg, x, y, lora)
+    assert rel_l2(logits.cpu(), lg_sim) < TOL_SIM_LOGITS
+    assert rel_l2(logits.cpu(), lg_ref) < TOL_FP32
+    assert rel_l2(gx.cpu(), g_sim) < 1e-2
+    assert rel_l2(gx.cpu(), g_ref) < 2e-2
+    # the LoRA branch must matter in this case (otherwise the test proves nothing)
+    _, g_nolora, _ = O.loss_and_input_grad(w, cfg, x, y, None)
+    assert rel_l2(g_ref, g_nolora) > 5e-2
+
+
 def test_unnormalised_forward_equals_normalised_input():
     cfg, w, lora, x, y = make_case(batch=2)
     eng = make_engine(cfg, w, lora)
