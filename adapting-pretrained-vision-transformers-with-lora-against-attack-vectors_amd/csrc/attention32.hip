@@ -16,6 +16,7 @@
 // to both operands), and softmax statistics / LSE / delta are per-lane scalars.
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "kernels.h"
 #include "prof.h"
@@ -53,6 +54,37 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {   // registers
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = f2bf(v[8 * s + j]);
     return o;
+}
+// Per-lane element offsets of the two fragment kinds inside ONE 32-row tile of a swizzled image, computed once
+// per kernel.  swz() only looks at row bits 1..3, so they are the same for every 32-row tile and 16-row half:
+// inside the (fully unrolled) tile loops a fragment address is  image + constant + one of these 8 registers,
+// i.e. the ds_read's immediate offset -- no per-step address arithmetic (it was a quarter of the loop's VALU work).
+struct FragOffs {
+    int row[4];        // row fragment, k-step ks:  + tile * 2048
+    int tr[2][2];      // transposed fragment, feature half dt, the two 4-row reads:  + tile * 2048 + st * 1024
+};
+__device__ __forceinline__ FragOffs frag_offs(int lane) {
+    FragOffs o;
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) o.row[ks] = c * HD + (((2 * ks + h) ^ swz(c)) << 3);
+    const int g = lane >> 4, i = lane & 15;
+    const int th = g >> 1, q = i >> 2, p = i & 3;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int r = 4 * th + q + 8 * e;
+            o.tr[dt][e] = r * HD + (((dt * 4 + 2 * (g & 1) + (p >> 1)) ^ swz(r)) << 3) + ((p & 1) << 2);
+        }
+    return o;
+}
+__device__ __forceinline__ bf16x8 row_frag_o(const bf16* img, int tile, int off) {
+    return *(const bf16x8*)(img + tile * 32 * HD + off);
+}
+__device__ __forceinline__ bf16x8 tr_frag_o(const bf16* img, int tile, int st, const int (&off)[2]) {
+    const bf16* b = img + tile * 32 * HD + st * 16 * HD;
+    return cat4(lds_read_tr16(b + off[0]), lds_read_tr16(b + off[1]));
 }
 // fill rows [0, ROWS) of a swizzled image from global rows min(r, T-1) (row stride ld elements):
 // one 1 KiB direct-to-LDS load per 8 rows, groups dealt round-robin to NW waves.
@@ -133,7 +165,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void attn_fwd32_kernel(const bf16* 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int nkt = (T + 31) >> 5;                  // key tiles that hold at least one valid key
+    const FragOffs fo = frag_offs(lane);
     const int tcut = T - 4 * h;                     // key < T  <=>  kt*32 + (r&3) + 8*(r>>2) < tcut
     for (; qb < nqb; qb += FWD_WAVES) {
         // online softmax over 32-key tiles (running max m, running sum l per query = per lane pair)
@@ -143,17 +175,18 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void attn_fwd32_kernel(const bf16* 
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-#pragma unroll 1
-        for (int kt = 0; kt < nkt; ++kt) {
+        // one 32-key tile; MASKED: the last, partly filled one (keys >= T get -inf)
+        auto step = [&](int kt, auto masked) {
+            constexpr bool MASKED = decltype(masked)::value;
             // S^T tile: rows = keys, column = query c
             f32x16 s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s = mfma32(row_frag32(sK, kt * 32 + c, ks, h), qf[ks], s);
+            for (int ks = 0; ks < 4; ++ks) s = mfma32(row_frag_o(sK, kt, fo.row[ks]), qf[ks], s);
             // m, tmax are in RAW score units (the softmax scale is positive); p = exp2(s*c - m*c)
             float tmax = -INFINITY;
-            if (kt * 32 + 32 > T) {                 // partial tile (wave-uniform): mask keys >= T
+            if constexpr (MASKED) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if ((kt * 32 + (r & 3) + 8 * (r >> 2)) >= tcut) s[r] = -INFINITY;
@@ -181,9 +214,13 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void attn_fwd32_kernel(const bf16* 
             for (int st = 0; st < 2; ++st) {
                 const bf16x8 pb = pack8(s, st);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(tr_frag32(sV, kt * 32 + 16 * st, dt * 32, lane), pb, o[dt]);
+                for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(tr_frag_o(sV, kt, st, fo.tr[dt]), pb, o[dt]);
             }
-        }
+        };
+        const int nfull = T >> 5;
+#pragma unroll 1
+        for (int kt = 0; kt < nfull; ++kt) step(kt, std::false_type{});
+        if (T & 31) step(nfull, std::true_type{});
         l += __shfl_xor(l, 32, 64);
         const int q = qb * 32 + c;
         const float inv = 1.f / l;
@@ -204,11 +241,13 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
                                                          float scale_log2e) {
     constexpr int ROWS = NT * 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // image order: the pairs read together (Q with dO in phase B, K with V in phase A) sit one image (28 KiB) apart,
+    // inside the 64 KiB immediate-offset range of one address register
     bf16* sQ = (bf16*)smem;
-    bf16* sK = sQ + ROWS * HD;
+    bf16* sdO = sQ + ROWS * HD;
+    bf16* sK = sdO + ROWS * HD;
     bf16* sV = sK + ROWS * HD;
-    bf16* sdO = sV + ROWS * HD;
-    float* sLse = (float*)(sdO + ROWS * HD);
+    float* sLse = (float*)(sV + ROWS * HD);
     float* sDelta = sLse + ROWS;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -245,6 +284,8 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
     __syncthreads();
 
     const int nb = (T + 31) >> 5;
+    const FragOffs fo = frag_offs(lane);
+    const int tcut = T - 4 * h;                      // key index held in register r of a tile: kt*32 + (r&3) + 8*(r>>2) + 4*h
     for (int item = w; item < 2 * nb; item += 8) {
         if (item < nb) {
             // ---------------- phase B: key block on the lane ----------------
@@ -258,14 +299,14 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { dv[dt][r] = 0.f; dk[dt][r] = 0.f; }
 #pragma unroll 1
-            for (int qt = 0; qt < NT; ++qt) {
+            for (int qt = 0; qt < nb; ++qt) {
                 f32x16 s, dp;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    s = mfma32(row_frag32(sQ, qt * 32 + c, ks, h), kf[ks], s);       // S[q][key]
-                    dp = mfma32(row_frag32(sdO, qt * 32 + c, ks, h), vf[ks], dp);    // dP[q][key]
+                    s = mfma32(row_frag_o(sQ, qt, fo.row[ks]), kf[ks], s);                     // S[q][key]
+                    dp = mfma32(row_frag_o(sQ + ROWS * HD, qt, fo.row[ks]), vf[ks], dp);       // dP[q][key]  (sdO = sQ + one image)
                 }
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
@@ -283,8 +324,8 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
                     const bf16x8 pb = pack8(s, st), dsb = pack8(dp, st);
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) {
-                        dv[dt] = mfma32(tr_frag32(sdO, qt * 32 + 16 * st, dt * 32, lane), pb, dv[dt]);   // dV^T[d][key]
-                        dk[dt] = mfma32(tr_frag32(sQ, qt * 32 + 16 * st, dt * 32, lane), dsb, dk[dt]);   // dK^T[d][key]
+                        dv[dt] = mfma32(tr_frag_o(sQ + ROWS * HD, qt, st, fo.tr[dt]), pb, dv[dt]);   // dV^T[d][key]
+                        dk[dt] = mfma32(tr_frag_o(sQ, qt, st, fo.tr[dt]), dsb, dk[dt]);   // dK^T[d][key]
                     }
                 }
             }
@@ -313,31 +354,33 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
-#pragma unroll 1
-            for (int kt = 0; kt < NT; ++kt) {
+            auto stepA = [&](int kt, auto masked) {
+                constexpr bool MASKED = decltype(masked)::value;
                 f32x16 s, dp;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    s = mfma32(row_frag32(sK, kt * 32 + c, ks, h), qf[ks], s);        // S^T[key][q]
-                    dp = mfma32(row_frag32(sV, kt * 32 + c, ks, h), dof[ks], dp);     // dP^T[key][q]
+                    s = mfma32(row_frag_o(sK, kt, fo.row[ks]), qf[ks], s);                     // S^T[key][q]
+                    dp = mfma32(row_frag_o(sK + ROWS * HD, kt, fo.row[ks]), dof[ks], dp);      // dP^T[key][q]  (sV = sK + one image)
                 }
-                const bool partial = kt * 32 + 32 > T;      // wave-uniform: only the last key tile is masked
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     float p = fexp2(fmaf(s[r], scale_log2e, -lse_q));
-                    if (partial && key >= T) p = 0.f;
-                    dp[r] = p * (dp[r] - delta_q);                          // dS / scale (folded into dQ below)
+                    if constexpr (MASKED) { if (kt * 32 + (r & 3) + 8 * (r >> 2) >= tcut) p = 0.f; }   // keys >= T
+                    dp[r] = p * (dp[r] - delta_q);                                            // dS / scale (folded into dQ below)
                 }
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
                     const bf16x8 dsb = pack8(dp, st);
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(tr_frag32(sK, kt * 32 + 16 * st, dt * 32, lane), dsb, dq[dt]);
+                    for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(tr_frag_o(sK, kt, st, fo.tr[dt]), dsb, dq[dt]);
                 }
-            }
+            };
+            const int nfull = T >> 5;
+#pragma unroll 1
+            for (int kt = 0; kt < nfull; ++kt) stepA(kt, std::false_type{});
+            if (T & 31) stepA(nfull, std::true_type{});       // the one partly filled key tile
             if (q < T) {
                 bf16* dst = dqkv + ((size_t)b * T + q) * ld + hd * HD + 4 * h;
 #pragma unroll
