@@ -21,6 +21,13 @@
 #include "kernels.h"
 #include "prof.h"
 
+#ifdef VITLORA_ATTN_STAMPS   // diagnostic build only (tools/attn_stamp.hip): per-wave s_memtime stamps
+__device__ unsigned long long g_attn_stamps[8192 * 8 * 8];
+#define STAMP(k) do { if (blockIdx.x < 8192 && (threadIdx.x & 63) == 0) g_attn_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int HD = 64;
@@ -258,31 +265,44 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
     const bf16* base = qkv + (size_t)b * T * ld + hd * HD;
     const bf16* dobase = dctx + (size_t)b * T * D + hd * HD;
     const bf16* obase = ctx + (size_t)b * T * D + hd * HD;
+    STAMP(0);
     stage_glds<ROWS, 8>(sQ, base, ld, T, w, lane);
     stage_glds<ROWS, 8>(sK, base + D, ld, T, w, lane);
     stage_glds<ROWS, 8>(sV, base + 2 * D, ld, T, w, lane);
     stage_glds<ROWS, 8>(sdO, dobase, D, T, w, lane);
-    // delta[r] = sum_d dO[r][d] * O[r][d]; LSE (rows >= T: +inf so that P = 0 there)
-    for (int idx = tid; idx < ROWS * 8; idx += 512) {
-        const int r = idx >> 3, cc = idx & 7;
-        float part = 0.f;
-        if (r < T) {
-            const bf16x8 dv = *(const bf16x8*)(dobase + (size_t)r * D + cc * 8);
-            const bf16x8 ov = *(const bf16x8*)(obase + (size_t)r * D + cc * 8);
+    // delta[r] = sum_d dO[r][d] * O[r][d]; LSE (rows >= T: +inf so that P = 0 there).  All of a thread's global
+    // loads go out before the first one is consumed: one memory round trip for the whole prologue, not one per
+    // pass (the passes used to serialise behind the in-order vmcnt: 4 round trips, a third of the kernel's time;
+    // measured with tools/attn_stamp.hip).
+    constexpr int NPASS = (ROWS * 8 + 511) / 512;
+    bf16x8 pdv[NPASS], pov[NPASS];
+    float plse[NPASS];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) part += bf2f(dv[k]) * bf2f(ov[k]);
-        }
+    for (int j = 0; j < NPASS; ++j) {
+        const int idx = tid + j * 512, r = idx >> 3, cc = idx & 7;
+        const int rc = r < T ? r : T - 1;                  // clamped: every load is valid, masked below
+        pdv[j] = *(const bf16x8*)(dobase + (size_t)rc * D + cc * 8);
+        pov[j] = *(const bf16x8*)(obase + (size_t)rc * D + cc * 8);
+        plse[j] = lse2[((size_t)b * H + hd) * T + rc];
+    }
+#pragma unroll
+    for (int j = 0; j < NPASS; ++j) {
+        const int idx = tid + j * 512, r = idx >> 3, cc = idx & 7;
+        float part = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) part += bf2f(pdv[j][k]) * bf2f(pov[j][k]);
         part += __shfl_xor(part, 1, 64);
         part += __shfl_xor(part, 2, 64);
         part += __shfl_xor(part, 4, 64);
-        if (cc == 0) {
-            sDelta[r] = part;
-            sLse[r] = r < T ? lse2[((size_t)b * H + hd) * T + r] : INFINITY;
+        if (cc == 0 && r < ROWS) {
+            sDelta[r] = r < T ? part : 0.f;
+            sLse[r] = r < T ? plse[j] : INFINITY;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    STAMP(1);
     const int nb = (T + 31) >> 5;
     const FragOffs fo = frag_offs(lane);
     const int tcut = T - 4 * h;                      // key index held in register r of a tile: kt*32 + (r&3) + 8*(r>>2) + 4*h
@@ -329,6 +349,7 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
                     }
                 }
             }
+            STAMP(2);
             if (key < T) {
                 bf16* dst = dqkv + ((size_t)b * T + key) * ld + hd * HD + 4 * h;
 #pragma unroll
@@ -342,8 +363,10 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
                         *(bf16x4*)(dst + 2 * D + dt * 32 + 8 * rq) = vv;
                     }
             }
+            STAMP(3);
         } else {
             // ---------------- phase A: query block on the lane ----------------
+            STAMP(4);
             const int q = (item - nb) * 32 + c;
             bf16x8 qf[4], dof[4];
 #pragma unroll
@@ -381,6 +404,7 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
 #pragma unroll 1
             for (int kt = 0; kt < nfull; ++kt) stepA(kt, std::false_type{});
             if (T & 31) stepA(nfull, std::true_type{});       // the one partly filled key tile
+            STAMP(5);
             if (q < T) {
                 bf16* dst = dqkv + ((size_t)b * T + q) * ld + hd * HD + 4 * h;
 #pragma unroll
@@ -395,6 +419,7 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
             }
         }
     }
+    STAMP(6);
 }
 
 template <int NT>
