@@ -15,6 +15,7 @@ Extra objects in that line:
                 (vl_profile_begin/_report, include/vitlora.h) against the gfx950 dense bf16
                 MFMA peak; plus `path` = whole-path algorithmic FLOP/s and `pgd_step` =
                 the HBM-bound elementwise kernel against the 8 TB/s HBM peak.
+  extras        secondary measurements (merged-LoRA attack, one LoRA train step); not `value`.
   cpu_baseline  the CPU oracle (oracle/, a torch restatement of the reference path) timed on
                 this box's host cores on a bounded sample of the same workload.
 """
@@ -57,6 +58,63 @@ def algorithmic_flops_per_image_step(arch, r, targets):
     return fwd + bwd
 
 
+def extras(P, syn, arch, args, dev, x, y):
+    """Secondary measurements on rank 0 at N = 1 (never the headline `value`):
+    lora_merged  the same PGD attack with the adapters folded into W first (merge_and_unload,
+                 eval_compose.py:110): no LoRA K tiles, no down-projections;
+    lora_train_step  train_loras.py:303-315 on one GPU's share of BASELINE config 3 (64 images):
+                 forward(train, LoRA dropout 0.1) + CE + backward (LoRA + classifier grads) + fused Adam."""
+    res = {}
+    spec = P.LoraSpec(r=args.rank, alpha=16.0, dropout=0.0, targets=TARGETS, merged=True)
+    eng = P.Engine(arch, spec, device=dev)
+    eng.load_state_dict(syn.random_state_dict(arch, seed=0))
+    for (i, t), (A, Bm) in syn.random_lora(arch, args.rank, TARGETS, seed=1).items():
+        eng.param(i, t, "A").copy_(A)
+        eng.param(i, t, "B").copy_(Bm)
+    eng.commit()
+    adv = torch.empty_like(x)
+    eng.pgd_attack(x, y, EPS, ALPHA, args.pgd_steps, random_start=True, seed=1, out=adv)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.pgd_attack(x, y, EPS, ALPHA, args.pgd_steps, random_start=True, seed=2, out=adv)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res["lora_merged"] = {"value": x.shape[0] / dt, "unit": "img/s", "ms_per_step": 1e3 * dt}
+    del eng
+    log(f"extras: merged-LoRA attack {x.shape[0] / dt:.1f} img/s")
+
+    bt = 64
+    eng = P.Engine(arch, P.LoraSpec(r=args.rank, alpha=16.0, dropout=0.1, targets=TARGETS), device=dev)
+    eng.load_state_dict(syn.random_state_dict(arch, seed=0))
+    for (i, t), (A, Bm) in syn.random_lora(arch, args.rank, TARGETS, seed=1).items():
+        eng.param(i, t, "A").copy_(A)
+        eng.param(i, t, "B").copy_(Bm)
+    eng.commit()
+    xt, yt = x[:bt], y[:bt]
+    m1, m2 = torch.zeros_like(eng.flat), torch.zeros_like(eng.flat)
+
+    def train_step(t):
+        eng.forward(xt, normalise=True, train=True)
+        eng.loss_ce(yt)
+        _, g = eng.backward(False, True)
+        eng.adam_step(eng.flat, g, m1, m2, 1e-4, 0.9, 0.999, 1e-8, t)
+        eng.commit()
+
+    for t in range(1, 3):
+        train_step(t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 10
+    for t in range(3, 3 + n):
+        train_step(t)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    res["lora_train_step"] = {"value": bt / dt, "unit": "img/s", "ms_per_step": 1e3 * dt, "batch": bt,
+                              "what": "forward(train, dropout 0.1) + CE + LoRA/classifier backward + Adam, clean inputs"}
+    log(f"extras: LoRA train step {1e3 * dt:.2f} ms at batch {bt}")
+    return res
+
+
 T_START = time.perf_counter()
 
 
@@ -91,6 +149,7 @@ def main():
     ap.add_argument("--merged", action="store_true", help="fold LoRA into W (merge_and_unload) instead of fusing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (merged-LoRA attack, LoRA train step)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -186,6 +245,9 @@ def main():
                 "unit": "GB/s", "frac": ps["bytes"] / (ps["ms"] * 1e-3) / PEAK_HBM, "avg_launch_ms": ps["ms"] / ps["n"]},
             "kernels_ms_per_pgd_iteration": {k: round(v["ms"] / 2, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
         }
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        out["extras"] = extras(P, syn, arch, args, dev, x, y)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(arch, args)

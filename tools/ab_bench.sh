@@ -5,8 +5,8 @@ P=adapting-pretrained-vision-transformers-with-lora-against-attack-vectors_amd
 A=$PWD/$P/csrc/build/libA.so
 N=${1:-2}
 for i in $(seq 1 $N); do
-  timeout -k 10 200 python bench.py --steps 1 --warmup 1 --pgd-steps 4 --no-cpu-baseline > gpurun_out/ab_B$i.log 2>/dev/null || exit 1
-  VITLORA_LIB=$A timeout -k 10 200 python bench.py --steps 1 --warmup 1 --pgd-steps 4 --no-cpu-baseline > gpurun_out/ab_A$i.log 2>/dev/null || exit 1
+  timeout -k 10 200 python bench.py --steps 1 --warmup 1 --pgd-steps 4 --no-cpu-baseline --no-extras > gpurun_out/ab_B$i.log 2>/dev/null || exit 1
+  VITLORA_LIB=$A timeout -k 10 200 python bench.py --steps 1 --warmup 1 --pgd-steps 4 --no-cpu-baseline --no-extras > gpurun_out/ab_A$i.log 2>/dev/null || exit 1
 done
 python - <<'PY'
 import json, glob
