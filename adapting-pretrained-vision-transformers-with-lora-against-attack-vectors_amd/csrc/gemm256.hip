@@ -30,6 +30,13 @@
 #include "gemm_epi.h"
 #include "prof.h"
 
+#ifdef VITLORA_GEMM_STAMPS   // diagnostic build only (tools/gemm_stamp.hip): per-wave s_memtime stamps, 4 per output tile
+__device__ unsigned long long g_gemm_stamps[256 * 8 * 16 * 4];
+#define GSTAMP(it, k) do { if (blockIdx.x < 256 && (it) < 16 && (threadIdx.x & 63) == 0) g_gemm_stamps[((blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (it)) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GSTAMP(it, k) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int BN = 256;
@@ -142,7 +149,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
 
     // One output tile: main loop over K (its first 6 half-tiles are already issued), then
     // `issue_next()` (starts the next tile's loads), then the epilogue.
-    auto run_tile = [&](int bm, int bn, bool first, auto&& issue_next) {
+    auto run_tile = [&](int bm, int bn, bool first, int it_, auto&& issue_next) {
+        GSTAMP(it_, 0);
         constexpr int BUF = (BM + BN) * BK;
         constexpr int MI = BM / 64;             // 16-row MFMA tiles per output quadrant (m)
         constexpr int NA = BM / 128, NW = 2;
@@ -240,7 +248,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
         ktile(nk - 1, IC<2>{}, IC<0>{});
         if (wm == 0) BARRIER();                      // waves 0-3 rejoin (equal barrier counts)
         // every wave passed the last barrier only after its final ds_reads completed: LDS may be refilled
+        GSTAMP(it_, 1);
         issue_next();
+        GSTAMP(it_, 2);
 
         f32x4 bv[4];
 #pragma unroll
@@ -258,6 +268,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
             for (int j = 0; j < 4; ++j) v[j] = acc[i][j] + bv[j];
             epilogue_row16<EPI>(p, m, n0, v);
         }
+        GSTAMP(it_, 3);
     };
 
     // Workgroups that share an XCD (blockIdx % 8 under round-robin placement; a speed assumption
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
     prologue(bm0 + cur / tilesN, cur % tilesN);
     for (int it = 0; cur >= 0; ++it) {
         const int nxt = tile_of(it + 1);
-        run_tile(bm0 + cur / tilesN, cur % tilesN, it == 0, [&]() {
+        run_tile(bm0 + cur / tilesN, cur % tilesN, it == 0, it, [&]() {
             if (nxt >= 0) prologue(bm0 + nxt / tilesN, nxt % tilesN);
         });
         cur = nxt;
