@@ -115,6 +115,16 @@ def extras(P, syn, arch, args, dev, x, y):
     return res
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+    tools/pmc_traffic.py; counters cannot be read from inside this process).  None if not on file."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
+        return t[kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 T_START = time.perf_counter()
 
 
@@ -235,7 +245,7 @@ def main():
         ps = prof.get("pgd_step_kernel")
         out["roofline"] = {
             "bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
-            "frac": ach * 1e12 / PEAK_BF16_DENSE, "traffic": None,
+            "frac": ach * 1e12 / PEAK_BF16_DENSE, "traffic": pmc_traffic(dom),
             "launches": d["n"], "avg_launch_ms": d["ms"] / d["n"], "share_of_step_time": d["ms"] / tot_ms,
             "path": {"achieved": value * args.pgd_steps * flops_img_step / 1e12, "unit": "TFLOP/s",
                      "frac": value * args.pgd_steps * flops_img_step / (world * PEAK_BF16_DENSE),
