@@ -285,6 +285,7 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
         pov[j] = *(const bf16x8*)(obase + (size_t)rc * D + cc * 8);
         plse[j] = lse2[((size_t)b * H + hd) * T + rc];
     }
+    STAMP(7);
 #pragma unroll
     for (int j = 0; j < NPASS; ++j) {
         const int idx = tid + j * 512, r = idx >> 3, cc = idx & 7;

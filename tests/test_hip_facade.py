@@ -183,3 +183,37 @@ def test_lora_training_steps_match_oracle():
             want = ol.ab[(i, t)][idx] - lora.ab[(i, t)][idx]
             cos = float((got * want).sum() / (got.norm() * want.norm() + 1e-30))
             assert cos > 0.9, (i, t, which, cos)
+
+
+def test_sequential_adapter_merge_matches_summed_update(tmp_path):
+    """eval_compose.py:102-114: adapters merged one after the other == W + s*B1*A1 + s*B2*A2 (oracle arithmetic)."""
+    P = pkg()
+    cfg, w, lora1, x, y = make_case(batch=3, seed=5)
+    lora2 = O.init_lora(cfg, r=lora1.r, targets=lora1.targets, seed=77, b_std=0.05)
+    dirs = []
+    for k, lora in enumerate((lora1, lora2)):
+        pm = P.setup_peft_lora(_model(cfg, w), rank=lora.r, alpha=lora.alpha, dropout=0.0)
+        eng = pm._vit._engine()
+        for (i, t), (A, B) in lora.ab.items():
+            eng.param(i, t, "A").copy_(A)
+            eng.param(i, t, "B").copy_(B)
+        pm._vit.mark_dirty()
+        d = str(tmp_path / f"adapter{k}")
+        pm.save_pretrained(d)
+        dirs.append(d)
+    import eval_compose
+    merged = eval_compose.merge_lora_adapters(_model(cfg, w), dirs)
+    xn = O.normalise(x)
+    got = merged(xn.cuda()).logits.detach().cpu()
+    w2 = {k: v.clone() for k, v in w.items()}
+    for lora in (lora1, lora2):
+        for (i, t), (A, B) in lora.ab.items():
+            key = f"vit.encoder.layer.{i}." + dict(O.LINEAR_MODULES)[t] + ".weight"
+            w2[key] = w2[key] + lora.scaling * (B @ A)
+    ref = O.vit_forward(w2, cfg, xn, None)
+    assert rel_l2(got, ref) < 1e-2
+    # and the merge changed the model (both adapters matter)
+    assert rel_l2(ref, O.vit_forward(w, cfg, xn, None)) > 5e-2
+    # accuracy / weighted-F1 helper against hand-computed values
+    acc, f1 = eval_compose.accuracy_and_weighted_f1([0, 0, 1, 1, 2], [0, 1, 1, 1, 0], 3)
+    assert abs(acc - 0.6) < 1e-6 and abs(f1 - (0.5 * 2 / 5 + 0.8 * 2 / 5 + 0.0)) < 1e-6

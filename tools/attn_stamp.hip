@@ -29,16 +29,16 @@ int main() {
     std::vector<unsigned long long> st(8192 * 8 * 8);
     hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_attn_stamps), st.size() * 8);
     const int nblk = B * H < 8192 ? B * H : 8192;
-    const char* names[] = {"stage+barrier (0->1)", "B main loop (1->2)", "B stores (2->3)", "A main loop (4->5)", "A stores (5->6)", "whole wave (0->6)"};
-    const int a[] = {0, 1, 2, 4, 5, 0}, b[] = {1, 2, 3, 5, 6, 6};
+    const char* names[] = {"issue loads (0->7)", "stage+barrier (0->1)", "B main loop (1->2)", "B stores (2->3)", "A main loop (4->5)", "A stores (5->6)", "whole wave (0->6)"};
+    const int a[] = {0, 0, 1, 2, 4, 5, 0}, b[] = {7, 1, 2, 3, 5, 6, 6};
     for (int wv = 0; wv < 8; wv += (wv == 0 ? 6 : 1)) {       // wave 0 (two items), 6 (B only), 7 (A only)
         printf("wave %d:", wv);
-        for (int k = 0; k < 6; ++k) {
+        for (int k = 0; k < 7; ++k) {
             double sum = 0; int n = 0;
             for (int blk = 256; blk < nblk; ++blk) {          // skip the first wave of workgroups (cold start)
                 const unsigned long long* s = &st[(blk * 8 + wv) * 8];
-                if (wv == 6 && (k == 3 || k == 4)) continue;
-                if (wv == 7 && (k == 1 || k == 2)) continue;
+                if (wv == 6 && (k == 4 || k == 5)) continue;
+                if (wv == 7 && (k == 2 || k == 3)) continue;
                 if (s[b[k]] > s[a[k]]) { sum += (double)(s[b[k]] - s[a[k]]); ++n; }
             }
             if (n) printf("  %s %.0f", names[k], sum / n);
