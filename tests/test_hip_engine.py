@@ -96,6 +96,24 @@ def test_lora_down_fusion_variants(r, targets):
     assert rel_l2(g_ref, g_nolora) > 5e-2
 
 
+@pytest.mark.parametrize("hidden,heads,mlp,layers,r", [(256, 4, 1024, 2, 8), (1024, 16, 4096, 1, 16)])
+def test_other_widths_run_the_256_row_gemm(hidden, heads, mlp, layers, r):
+    """Widths other than ViT-B's: hidden 256 (K only 4-5 tiles deep: the shortest pipeline the 256-row GEMM accepts)
+    and the ViT-L/16 width (hidden 1024, 16 heads, mlp 4096, LoRA r = 16: BASELINE config 5's model family)."""
+    cfg, w, lora, x, y = make_case(image_size=224, hidden=hidden, heads=heads, mlp=mlp, layers=layers, batch=3, r=r,
+                                   std=0.03 if hidden == 1024 else 0.05)
+    eng = make_engine(cfg, w, lora)
+    logits = eng.forward(x.cuda(), normalise=True)
+    eng.loss_ce(y.cuda())
+    gx, _ = eng.backward(True, False, tuple(x.shape))
+    torch.cuda.synchronize()
+    _, g_ref, lg_ref = O.loss_and_input_grad(w, cfg, x, y, lora)
+    assert rel_l2(logits.cpu(), lg_ref) < TOL_FP32
+    assert rel_l2(gx.cpu(), g_ref) < 2e-2
+    big = g_ref.abs() > 0.05 * g_ref.abs().mean()
+    assert (torch.sign(gx.cpu())[big] == torch.sign(g_ref)[big]).float().mean().item() > 0.97
+
+
 def test_unnormalised_forward_equals_normalised_input():
     cfg, w, lora, x, y = make_case(batch=2)
     eng = make_engine(cfg, w, lora)
