@@ -109,6 +109,30 @@ def extras(P, syn, arch, args, dev, x, y):
         train_step(t)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
+    if args.vitl:
+        # BASELINE config 5's model family (ViT-L/16 + LoRA r = 16, 128 images per GPU): the same PGD attack
+        del eng
+        archl = P.ArchConfig(hidden=1024, layers=24, heads=16, mlp=4096, num_labels=21)
+        engl = P.Engine(archl, P.LoraSpec(r=16, alpha=16.0, dropout=0.0, targets=TARGETS), device=dev)
+        engl.load_state_dict(syn.random_state_dict(archl, seed=0))
+        for (i, t), (A, Bm) in syn.random_lora(archl, 16, TARGETS, seed=1).items():
+            engl.param(i, t, "A").copy_(A)
+            engl.param(i, t, "B").copy_(Bm)
+        engl.commit()
+        xl, yl = x[:128].contiguous(), y[:128].contiguous()
+        advl = torch.empty_like(xl)
+        engl.pgd_attack(xl, yl, EPS, ALPHA, args.pgd_steps, random_start=True, seed=1, out=advl)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        engl.pgd_attack(xl, yl, EPS, ALPHA, args.pgd_steps, random_start=True, seed=2, out=advl)
+        torch.cuda.synchronize()
+        dtl = time.perf_counter() - t0
+        fl = algorithmic_flops_per_image_step(archl, 16, TARGETS)
+        res["vit_l16_lora_r16_pgd"] = {"value": 128 / dtl, "unit": "img/s", "ms_per_step": 1e3 * dtl, "batch": 128,
+                                       "tflops": 128 / dtl * args.pgd_steps * fl / 1e12}
+        log(f"extras: ViT-L/16 + LoRA r=16 PGD-{args.pgd_steps} at batch 128: {128 / dtl:.1f} img/s")
+        del engl
+        eng = None
     res["lora_train_step"] = {"value": bt / dt, "unit": "img/s", "ms_per_step": 1e3 * dt, "batch": bt,
                               "what": "forward(train, dropout 0.1) + CE + LoRA/classifier backward + Adam, clean inputs"}
     log(f"extras: LoRA train step {1e3 * dt:.2f} ms at batch {bt}")
@@ -159,6 +183,7 @@ def main():
     ap.add_argument("--merged", action="store_true", help="fold LoRA into W (merge_and_unload) instead of fusing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--vitl", action="store_true", help="extras: also time the attack on ViT-L/16 + LoRA r=16 at batch 128")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (merged-LoRA attack, LoRA train step)")
     args = ap.parse_args()
 
