@@ -114,6 +114,28 @@ def test_other_widths_run_the_256_row_gemm(hidden, heads, mlp, layers, r):
     assert (torch.sign(gx.cpu())[big] == torch.sign(g_ref)[big]).float().mean().item() > 0.97
 
 
+def test_ragged_batches_replanning_and_empty_input():
+    """Batch sizes the tile sizes do not divide (1, 5, 7 images = 17 .. 119 token rows), a workspace that grows when a
+    larger batch arrives and is reused for smaller ones, and an empty batch (refused, not a crash)."""
+    cfg, w, lora, x, y = make_case(image_size=64, batch=7)
+    eng = make_engine(cfg, w, lora)
+    ref = O.vit_forward(w, cfg, O.normalise(x), lora)
+    for b in (1, 5, 7, 2):                       # grows the plan at 5 and 7, reuses it at 2
+        got = eng.forward(x[:b].cuda(), normalise=True).cpu()
+        assert rel_l2(got, ref[:b]) < TOL_FP32, b
+    # attack on a ragged batch stays in the eps-ball and is the slice of the larger batch
+    adv7 = eng.pgd_attack(x.cuda(), y.cuda(), 8 / 255, 2 / 255, 3, random_start=False).clone()
+    adv3 = eng.pgd_attack(x[2:5].cuda(), y[2:5].cuda(), 8 / 255, 2 / 255, 3, random_start=False)
+    assert (adv7 - x.cuda()).abs().max().item() <= 8 / 255 + 1e-6
+    assert (torch.sign(adv3 - x[2:5].cuda()) == torch.sign(adv7[2:5] - x[2:5].cuda())).float().mean().item() > 0.99
+    with pytest.raises(Exception):
+        eng.forward(x[:0].cuda(), normalise=True)
+    with pytest.raises(ValueError):
+        eng.forward(torch.zeros(2, 3, 32, 32).cuda(), normalise=True)
+    # the engine still works after the refused calls
+    assert rel_l2(eng.forward(x[:3].cuda(), normalise=True).cpu(), ref[:3]) < TOL_FP32
+
+
 def test_unnormalised_forward_equals_normalised_input():
     cfg, w, lora, x, y = make_case(batch=2)
     eng = make_engine(cfg, w, lora)
