@@ -85,6 +85,21 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
     }
 }
 
+// GELU_BWD on 16 columns with gelu'(z) already in registers (z0 = columns 0..7, z1 = 8..15)
+__device__ __forceinline__ void epilogue_gelu_bwd16(const GemmArgs& p, int m, int n0, const f32x4 (&v)[4], bf16x8 z0, bf16x8 z1) {
+    bf16x8 lo, hi;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        lo[k] = f2bf(v[0][k] * bf2f(z0[k]));
+        lo[4 + k] = f2bf(v[1][k] * bf2f(z0[4 + k]));
+        hi[k] = f2bf(v[2][k] * bf2f(z1[k]));
+        hi[4 + k] = f2bf(v[3][k] * bf2f(z1[4 + k]));
+    }
+    bf16* dst = (bf16*)p.C + (size_t)m * p.ldc + n0;
+    *(bf16x8*)dst = lo;
+    *(bf16x8*)(dst + 8) = hi;
+}
+
 // 16 consecutive output columns n0..n0+15 of row m held by one lane as v[0..3] (the 256-row
 // kernel permutes the W rows of its LDS image so that a lane's four column tiles are adjacent):
 // 16-byte loads / stores, 64 B (bf16) or 256 B (f32) contiguous per row and lane quad.
@@ -134,18 +149,7 @@ __device__ __forceinline__ void epilogue_row16(const GemmArgs& p, int m, int n0,
     } else if constexpr (EPI == EPI_GELU_BWD) {
         // R = gelu'(z) saved by the forward epilogue
         const bf16* zs = (const bf16*)p.R + (size_t)m * p.ldr + n0;
-        const bf16x8 z0 = *(const bf16x8*)zs, z1 = *(const bf16x8*)(zs + 8);
-        f32x4 o[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            o[0][k] = v[0][k] * bf2f(z0[k]);
-            o[1][k] = v[1][k] * bf2f(z0[4 + k]);
-            o[2][k] = v[2][k] * bf2f(z1[k]);
-            o[3][k] = v[3][k] * bf2f(z1[4 + k]);
-        }
-        bf16* dst = (bf16*)p.C + (size_t)m * p.ldc + n0;
-        *(bf16x8*)dst = pack8(o[0], o[1]);
-        *(bf16x8*)(dst + 8) = pack8(o[2], o[3]);
+        epilogue_gelu_bwd16(p, m, n0, v, *(const bf16x8*)zs, *(const bf16x8*)(zs + 8));
     } else if constexpr (EPI == EPI_NONE) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) asm volatile("" ::"v"(v[q]));
