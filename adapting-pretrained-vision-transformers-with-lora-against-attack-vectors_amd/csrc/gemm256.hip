@@ -264,23 +264,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
             // the saved gelu'(z) of a whole half of the wave's rows is requested before any of it is used or any
             // result is stored (the stores may alias as far as the compiler knows, so it would not hoist the loads
             // itself): two memory round trips per output tile instead of eight
+            bf16x8 rz[2 * MI][2];
 #pragma unroll
-            for (int hb = 0; hb < 2; ++hb) {
-                bf16x8 rz[MI][2];
+            for (int i = 0; i < 2 * MI; ++i) {
+                const bf16* zs = (const bf16*)p.R + (size_t)(bm * BM + wm * (BM / 2) + i * 16 + fr) * p.ldr + n0;
+                rz[i][0] = *(const bf16x8*)zs;
+                rz[i][1] = *(const bf16x8*)(zs + 8);
+            }
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const bf16* zs = (const bf16*)p.R + (size_t)(bm * BM + wm * (BM / 2) + (hb * MI + i) * 16 + fr) * p.ldr + n0;
-                    rz[i][0] = *(const bf16x8*)zs;
-                    rz[i][1] = *(const bf16x8*)(zs + 8);
-                }
+            for (int i = 0; i < 2 * MI; ++i) {
+                const int m = bm * BM + wm * (BM / 2) + i * 16 + fr;
+                f32x4 v[4];
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int m = bm * BM + wm * (BM / 2) + (hb * MI + i) * 16 + fr;
-                    f32x4 v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = acc[hb * MI + i][j] + bv[j];
-                    epilogue_gelu_bwd16(p, m, n0, v, rz[i][0], rz[i][1]);
-                }
+                for (int j = 0; j < 4; ++j) v[j] = acc[i][j] + bv[j];
+                epilogue_gelu_bwd16(p, m, n0, v, rz[i][0], rz[i][1]);
             }
         } else {
 #pragma unroll
