@@ -121,8 +121,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     if constexpr (NG > 0) lora_down_load<NV, NG>(pr, nv, lane, P, D);
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
         const float* xr = x + (int64_t)row * D;
-        f32x4 v[NV];
+        f32x4 v[NV], gam[NV], bet[NV];
         float s = 0.f;
+        if (h) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {          // requested with the row, not after its two reductions
+                const int c = lane + i * 64;
+                gam[i] = c < nv ? *(const f32x4*)(gamma + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                bet[i] = c < nv ? *(const f32x4*)(beta + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
             if (c < nv) {
-                const f32x4 g = *(const f32x4*)(gamma + c * 4), b = *(const f32x4*)(beta + c * 4);
+                const f32x4 g = gam[i], b = bet[i];
                 bf16x4 o;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = f2bf((v[i][k] - mean) * rstd * g[k] + b[k]);
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
     for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
-            const f32x4 r = *(const f32x4*)(dres + off + c * 4);
+            const f32x4 r = *(const f32x4*)(dres + off + c * 4);     // (requesting it with the row's first loads costs a wave per SIMD: +30 %)
             f32x4 o; bf16x4 ob;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
