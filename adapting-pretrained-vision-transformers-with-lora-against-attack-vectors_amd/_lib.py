@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VITLORA_LIB") or os.path.join(_HERE, "libvitlora_hip.so")
 
 VL_T = {"q": 1, "k": 2, "v": 4, "o": 8, "fc1": 16, "fc2": 32}
+VL_PREC = {"f16": 0, "fp16": 0, "f32": 1, "fp32": 1}
 
 
 class VLConfig(C.Structure):
@@ -22,7 +23,8 @@ class VLConfig(C.Structure):
         ("num_labels", C.c_int32), ("ln_eps", C.c_float),
         ("lora_r", C.c_int32), ("lora_alpha", C.c_float), ("lora_dropout", C.c_float),
         ("lora_targets", C.c_uint32), ("lora_merged", C.c_int32),
-        ("reserved", C.c_int32 * 4),
+        ("precision", C.c_int32),          # VL_PREC_F16 = 0 (fp16 operands, fp32 accumulate), VL_PREC_F32 = 1 (parity mode)
+        ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -36,6 +38,8 @@ SIGNATURES = {
     "vl_param_tensor": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "vl_param_flat": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "vl_lora_commit": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vl_params_changed": (C.c_int, [C.c_void_p]),
+    "vl_debug_counter": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     "vl_merge_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vl_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "vl_set_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -39,8 +39,6 @@ def batched_fgsm_attack(model, images, labels, epsilon, mean, std):
     (whitebox_attacks.py:22-38).  One forward, CE, backward-to-input and one fused step."""
     vit = _unwrap(model)
     eng = vit._engine()
-    if vit.lora_spec.r > 0 and not getattr(vit, "_committed", False):
-        vit.commit()
     m = [float(v) for v in torch.as_tensor(mean).flatten().tolist()]
     s = [float(v) for v in torch.as_tensor(std).flatten().tolist()]
     eng.set_normalization(m, s)
@@ -70,8 +68,6 @@ class _Attack:
     def _prepare(self, images):
         vit = _unwrap(self.model)
         eng = vit._engine()
-        if vit.lora_spec.r > 0 and not getattr(vit, "_committed", False):
-            vit.commit()
         x = images.detach().to(device=eng.device, dtype=torch.float32).contiguous()
         if self._norm is not None:
             mean, std = self._norm

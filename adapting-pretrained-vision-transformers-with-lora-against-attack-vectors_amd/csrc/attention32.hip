@@ -1,9 +1,9 @@
-// Attention forward / backward, second generation: 32x32x16 bf16 MFMA (half the LDS bytes per
+// Attention forward / backward, second generation: 32x32x16 h16 MFMA (half the LDS bytes per
 // FLOP of the 16x16x32 version), K/V/Q/dO images filled by direct-to-LDS loads, 32-query /
 // 32-key work items.  Same math and same interfaces as attention.hip (HF eager attention,
 // modeling_vit.py:164-189, and its backward); T <= 224 tokens, head_dim 64.
 //
-// LDS image of one [rows][64] bf16 operand: rows of 128 B, 16-byte chunk c of row r stored at
+// LDS image of one [rows][64] h16 operand: rows of 128 B, 16-byte chunk c of row r stored at
 // chunk c ^ f(r), f(r) = ((r>>1)&1)<<2 | ((r>>2)&3).  With that f both access kinds used here
 // are bank-conflict free:
 //   * row fragments  (ds_read_b128, lane = row of a 32-row tile, all lanes of a half-wave the
@@ -33,33 +33,33 @@ namespace {
 constexpr int HD = 64;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+__device__ __forceinline__ f32x16 mfma32(h16x8 a, h16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 // raw v_exp_f32 (no denormal-range fix-up: results below 2^-126 flush to 0, exp2(-inf) = 0)
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ int swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 
 // row fragment of a 32-row tile: lane (r = lane&31, h = lane>>5) gets img[row0 + r][16*ks + 8*h .. +7]
-__device__ __forceinline__ bf16x8 row_frag32(const bf16* img, int row, int ks, int h) {
-    return *(const bf16x8*)(img + row * HD + (((2 * ks + h) ^ swz(row)) << 3));
+__device__ __forceinline__ h16x8 row_frag32(const h16* img, int row, int ks, int h) {
+    return *(const h16x8*)(img + row * HD + (((2 * ks + h) ^ swz(row)) << 3));
 }
 // transposed fragment: element j of lane (c = lane&31, h = lane>>5) = img[t0 + 8*(j>>2) + 4*h + (j&3)][c0 + c]
 // (t0 multiple of 16, c0 multiple of 32).  16-lane group g = lane>>4: columns c0 + 16*(g&1) + [0,16), h = g>>1;
 // lane i = 4q + p of the group supplies the address of row q, columns 4p..4p+3 of the 4 x 16 block.
-__device__ __forceinline__ bf16x8 tr_frag32(const bf16* img, int t0, int c0, int lane) {
+__device__ __forceinline__ h16x8 tr_frag32(const h16* img, int t0, int c0, int lane) {
     const int g = lane >> 4, i = lane & 15;
     const int h = g >> 1, q = i >> 2, p = i & 3;
     const int col = c0 + 16 * (g & 1) + 4 * p;
     const int r0 = t0 + 4 * h + q, r1 = r0 + 8;
-    const bf16* a0 = img + r0 * HD + (((col >> 3) ^ swz(r0)) << 3) + (col & 4);
-    const bf16* a1 = img + r1 * HD + (((col >> 3) ^ swz(r1)) << 3) + (col & 4);
+    const h16* a0 = img + r0 * HD + (((col >> 3) ^ swz(r0)) << 3) + (col & 4);
+    const h16* a1 = img + r1 * HD + (((col >> 3) ^ swz(r1)) << 3) + (col & 4);
     return cat4(lds_read_tr16(a0), lds_read_tr16(a1));
 }
-__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {   // registers 8s .. 8s+7
-    bf16x8 o;
+__device__ __forceinline__ h16x8 pack8(const f32x16& v, int s) {   // registers 8s .. 8s+7
+    h16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = f2bf(v[8 * s + j]);
+    for (int j = 0; j < 8; ++j) o[j] = f2h(v[8 * s + j]);
     return o;
 }
 // Per-lane element offsets of the two fragment kinds inside ONE 32-row tile of a swizzled image, computed once
@@ -86,17 +86,17 @@ __device__ __forceinline__ FragOffs frag_offs(int lane) {
         }
     return o;
 }
-__device__ __forceinline__ bf16x8 row_frag_o(const bf16* img, int tile, int off) {
-    return *(const bf16x8*)(img + tile * 32 * HD + off);
+__device__ __forceinline__ h16x8 row_frag_o(const h16* img, int tile, int off) {
+    return *(const h16x8*)(img + tile * 32 * HD + off);
 }
-__device__ __forceinline__ bf16x8 tr_frag_o(const bf16* img, int tile, int st, const int (&off)[2]) {
-    const bf16* b = img + tile * 32 * HD + st * 16 * HD;
+__device__ __forceinline__ h16x8 tr_frag_o(const h16* img, int tile, int st, const int (&off)[2]) {
+    const h16* b = img + tile * 32 * HD + st * 16 * HD;
     return cat4(lds_read_tr16(b + off[0]), lds_read_tr16(b + off[1]));
 }
 // fill rows [0, ROWS) of a swizzled image from global rows min(r, T-1) (row stride ld elements):
 // one 1 KiB direct-to-LDS load per 8 rows, groups dealt round-robin to NW waves.
 template <int ROWS, int NW>
-__device__ __forceinline__ void stage_glds(bf16* img, const bf16* src, int ld, int T, int w, int lane) {
+__device__ __forceinline__ void stage_glds(h16* img, const h16* src, int ld, int T, int w, int lane) {
     const int lr = lane >> 3, lc = lane & 7;
     for (int g = w; g < ROWS / 8; g += NW) {
         const int r = g * 8 + lr;
@@ -110,7 +110,7 @@ __device__ __forceinline__ void stage_glds(bf16* img, const bf16* src, int ld, i
 // 16-byte chunk ch of row r at ch ^ (r & 7)), then wave stores of 8 rows x 128 B each.  Row-per-lane 8-byte
 // stores touch 32 lines per instruction and run at a third of the rate (tools/store_bench.hip).  Measured:
 // forward -10 %; the backward (148 KB of LDS with 4 KiB images) did not gain and keeps its direct stores.
-__device__ __forceinline__ void store_rows32_half(char* img, const f32x16 (&acc)[2], float mul, bf16* dst0, int ld, int tok0,
+__device__ __forceinline__ void store_rows32_half(char* img, const f32x16 (&acc)[2], float mul, h16* dst0, int ld, int tok0,
                                                   int T, int lane) {
     const int c = lane & 31, h = lane >> 5;
     const int lr = lane >> 3, lc = lane & 7;
@@ -121,18 +121,18 @@ __device__ __forceinline__ void store_rows32_half(char* img, const f32x16 (&acc)
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
-                    bf16x4 o;
+                    h16x4 o;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = f2bf(acc[dt][4 * rq + k] * mul);
-                    *(bf16x4*)(img + (c & 15) * 128 + (((dt * 4 + rq) ^ (c & 7)) << 4) + 8 * h) = o;
+                    for (int k = 0; k < 4; ++k) o[k] = f2h(acc[dt][4 * rq + k] * mul);
+                    *(h16x4*)(img + (c & 15) * 128 + (((dt * 4 + rq) ^ (c & 7)) << 4) + 8 * h) = o;
                 }
         }
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
             const int row = ps * 8 + lr;
-            const bf16x8 v = *(const bf16x8*)(img + row * 128 + ((lc ^ lr) << 4));
+            const h16x8 v = *(const h16x8*)(img + row * 128 + ((lc ^ lr) << 4));
             const int tok = tok0 + p * 16 + row;
-            if (tok < T) *(bf16x8*)(dst0 + (size_t)tok * ld + lc * 8) = v;
+            if (tok < T) *(h16x8*)(dst0 + (size_t)tok * ld + lc * 8) = v;
         }
     }
 }
@@ -143,30 +143,30 @@ __device__ __forceinline__ void store_rows32_half(char* img, const f32x16 (&acc)
 // ------------------------------------------------------------------------------------------
 constexpr int FWD_WAVES = 8;
 template <int NT>
-__global__ __launch_bounds__(64 * FWD_WAVES) void attn_fwd32_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ ctx,
+__global__ __launch_bounds__(64 * FWD_WAVES) void attn_fwd32_kernel(const h16* __restrict__ qkv, h16* __restrict__ ctx,
                                                             float* __restrict__ lse2, int T, int H, int D, float scale_log2e) {
     constexpr int ROWS = NT * 32;
-    __shared__ __attribute__((aligned(16))) bf16 sm[2 * ROWS * HD];
+    __shared__ __attribute__((aligned(16))) h16 sm[2 * ROWS * HD];
     __shared__ __attribute__((aligned(16))) char wimg[FWD_WAVES * 2048];     // per-wave output images (store_rows32_half)
-    bf16* sK = sm;
-    bf16* sV = sm + ROWS * HD;
+    h16* sK = sm;
+    h16* sV = sm + ROWS * HD;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
     const int b = blockIdx.x / H, hd = blockIdx.x - b * H;
     const int ld = 3 * D;
-    const bf16* base = qkv + (size_t)b * T * ld + hd * HD;
+    const h16* base = qkv + (size_t)b * T * ld + hd * HD;
     stage_glds<ROWS, FWD_WAVES>(sK, base + D, ld, T, w, lane);
     stage_glds<ROWS, FWD_WAVES>(sV, base + 2 * D, ld, T, w, lane);
 
     const int nqb = (T + 31) >> 5;
     int qb = w;
-    bf16x8 qf[4];
+    h16x8 qf[4];
     auto load_q = [&](int blk) {
         const int q = blk * 32 + c;
-        const bf16* qr = base + (size_t)(q < T ? q : T - 1) * ld + 8 * h;
+        const h16* qr = base + (size_t)(q < T ? q : T - 1) * ld + 8 * h;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qr + 16 * ks);
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const h16x8*)(qr + 16 * ks);
     };
     if (qb < nqb) load_q(qb);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void attn_fwd32_kernel(const bf16* 
             // O^T += V^T P^T: rows = d, column = query c
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                const bf16x8 pb = pack8(s, st);
+                const h16x8 pb = pack8(s, st);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(tr_frag_o(sV, kt, st, fo.tr[dt]), pb, o[dt]);
             }
@@ -242,18 +242,18 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void attn_fwd32_kernel(const bf16* 
 // dK, dV; key on the lane) and NB query blocks (phase A: dQ; query on the lane), 32 tokens each.
 // ------------------------------------------------------------------------------------------
 template <int NT>
-__global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ ctx,
-                                                         const bf16* __restrict__ dctx, const float* __restrict__ lse2,
-                                                         bf16* __restrict__ dqkv, int T, int H, int D, float scale,
+__global__ __launch_bounds__(512) void attn_bwd32_kernel(const h16* __restrict__ qkv, const h16* __restrict__ ctx,
+                                                         const h16* __restrict__ dctx, const float* __restrict__ lse2,
+                                                         h16* __restrict__ dqkv, int T, int H, int D, float scale,
                                                          float scale_log2e) {
     constexpr int ROWS = NT * 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // image order: the pairs read together (Q with dO in phase B, K with V in phase A) sit one image (28 KiB) apart,
     // inside the 64 KiB immediate-offset range of one address register
-    bf16* sQ = (bf16*)smem;
-    bf16* sdO = sQ + ROWS * HD;
-    bf16* sK = sdO + ROWS * HD;
-    bf16* sV = sK + ROWS * HD;
+    h16* sQ = (h16*)smem;
+    h16* sdO = sQ + ROWS * HD;
+    h16* sK = sdO + ROWS * HD;
+    h16* sV = sK + ROWS * HD;
     float* sLse = (float*)(sV + ROWS * HD);
     float* sDelta = sLse + ROWS;
 
@@ -262,9 +262,9 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
     const int c = lane & 31, h = lane >> 5;
     const int b = blockIdx.x / H, hd = blockIdx.x - b * H;
     const int ld = 3 * D;
-    const bf16* base = qkv + (size_t)b * T * ld + hd * HD;
-    const bf16* dobase = dctx + (size_t)b * T * D + hd * HD;
-    const bf16* obase = ctx + (size_t)b * T * D + hd * HD;
+    const h16* base = qkv + (size_t)b * T * ld + hd * HD;
+    const h16* dobase = dctx + (size_t)b * T * D + hd * HD;
+    const h16* obase = ctx + (size_t)b * T * D + hd * HD;
     STAMP(0);
     stage_glds<ROWS, 8>(sQ, base, ld, T, w, lane);
     stage_glds<ROWS, 8>(sK, base + D, ld, T, w, lane);
@@ -275,14 +275,14 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
     // pass (the passes used to serialise behind the in-order vmcnt: 4 round trips, a third of the kernel's time;
     // measured with tools/attn_stamp.hip).
     constexpr int NPASS = (ROWS * 8 + 511) / 512;
-    bf16x8 pdv[NPASS], pov[NPASS];
+    h16x8 pdv[NPASS], pov[NPASS];
     float plse[NPASS];
 #pragma unroll
     for (int j = 0; j < NPASS; ++j) {
         const int idx = tid + j * 512, r = idx >> 3, cc = idx & 7;
         const int rc = r < T ? r : T - 1;                  // clamped: every load is valid, masked below
-        pdv[j] = *(const bf16x8*)(dobase + (size_t)rc * D + cc * 8);
-        pov[j] = *(const bf16x8*)(obase + (size_t)rc * D + cc * 8);
+        pdv[j] = *(const h16x8*)(dobase + (size_t)rc * D + cc * 8);
+        pov[j] = *(const h16x8*)(obase + (size_t)rc * D + cc * 8);
         plse[j] = lse2[((size_t)b * H + hd) * T + rc];
     }
     STAMP(7);
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
         const int idx = tid + j * 512, r = idx >> 3, cc = idx & 7;
         float part = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) part += bf2f(pdv[j][k]) * bf2f(pov[j][k]);
+        for (int k = 0; k < 8; ++k) part += h2f(pdv[j][k]) * h2f(pov[j][k]);
         part += __shfl_xor(part, 1, 64);
         part += __shfl_xor(part, 2, 64);
         part += __shfl_xor(part, 4, 64);
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
         if (item < nb) {
             // ---------------- phase B: key block on the lane ----------------
             const int key = item * 32 + c;
-            bf16x8 kf[4], vf[4];
+            h16x8 kf[4], vf[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) { kf[ks] = row_frag32(sK, key, ks, h); vf[ks] = row_frag32(sV, key, ks, h); }
             f32x16 dv[2], dk[2];
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
                 }
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
-                    const bf16x8 pb = pack8(s, st), dsb = pack8(dp, st);
+                    const h16x8 pb = pack8(s, st), dsb = pack8(dp, st);
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) {
                         dv[dt] = mfma32(tr_frag_o(sQ + ROWS * HD, qt, st, fo.tr[dt]), pb, dv[dt]);   // dV^T[d][key]
@@ -352,16 +352,16 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
             }
             STAMP(2);
             if (key < T) {
-                bf16* dst = dqkv + ((size_t)b * T + key) * ld + hd * HD + 4 * h;
+                h16* dst = dqkv + ((size_t)b * T + key) * ld + hd * HD + 4 * h;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                     for (int rq = 0; rq < 4; ++rq) {
-                        bf16x4 kv, vv;
+                        h16x4 kv, vv;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) { kv[k] = f2bf(dk[dt][4 * rq + k] * scale); vv[k] = f2bf(dv[dt][4 * rq + k]); }
-                        *(bf16x4*)(dst + D + dt * 32 + 8 * rq) = kv;
-                        *(bf16x4*)(dst + 2 * D + dt * 32 + 8 * rq) = vv;
+                        for (int k = 0; k < 4; ++k) { kv[k] = f2h(dk[dt][4 * rq + k] * scale); vv[k] = f2h(dv[dt][4 * rq + k]); }
+                        *(h16x4*)(dst + D + dt * 32 + 8 * rq) = kv;
+                        *(h16x4*)(dst + 2 * D + dt * 32 + 8 * rq) = vv;
                     }
             }
             STAMP(3);
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
             // ---------------- phase A: query block on the lane ----------------
             STAMP(4);
             const int q = (item - nb) * 32 + c;
-            bf16x8 qf[4], dof[4];
+            h16x8 qf[4], dof[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) { qf[ks] = row_frag32(sQ, q, ks, h); dof[ks] = row_frag32(sdO, q, ks, h); }
             const float lse_q = sLse[q], delta_q = sDelta[q];
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
                 }
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
-                    const bf16x8 dsb = pack8(dp, st);
+                    const h16x8 dsb = pack8(dp, st);
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(tr_frag_o(sK, kt, st, fo.tr[dt]), dsb, dq[dt]);
                 }
@@ -407,15 +407,15 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
             if (T & 31) stepA(nfull, std::true_type{});       // the one partly filled key tile
             STAMP(5);
             if (q < T) {
-                bf16* dst = dqkv + ((size_t)b * T + q) * ld + hd * HD + 4 * h;
+                h16* dst = dqkv + ((size_t)b * T + q) * ld + hd * HD + 4 * h;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                     for (int rq = 0; rq < 4; ++rq) {
-                        bf16x4 ov;
+                        h16x4 ov;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) ov[k] = f2bf(dq[dt][4 * rq + k] * scale);
-                        *(bf16x4*)(dst + dt * 32 + 8 * rq) = ov;
+                        for (int k = 0; k < 4; ++k) ov[k] = f2h(dq[dt][4 * rq + k] * scale);
+                        *(h16x4*)(dst + dt * 32 + 8 * rq) = ov;
                     }
             }
         }
@@ -424,10 +424,10 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const bf16* __restrict_
 }
 
 template <int NT>
-size_t bwd_lds() { return (size_t)4 * NT * 32 * HD * sizeof(bf16) + (size_t)2 * NT * 32 * sizeof(float); }
+size_t bwd_lds() { return (size_t)4 * NT * 32 * HD * sizeof(h16) + (size_t)2 * NT * 32 * sizeof(float); }
 
 template <int NT>
-void launch_bwd(const bf16* qkv, const bf16* ctx, const bf16* dctx, const float* lse2, bf16* dqkv, int B, int T, int H,
+void launch_bwd(const h16* qkv, const h16* ctx, const h16* dctx, const float* lse2, h16* dqkv, int B, int T, int H,
                 int D, hipStream_t s) {
     const float scale = 0.125f;   // 64^-1/2
     hipLaunchKernelGGL((attn_bwd32_kernel<NT>), dim3(B * H), dim3(512), bwd_lds<NT>(), s, qkv, ctx, dctx, lse2, dqkv, T,
@@ -436,15 +436,19 @@ void launch_bwd(const bf16* qkv, const bf16* ctx, const bf16* dctx, const float*
 
 }  // namespace
 
-void attention32_init() {
-    static bool done = false;
-    if (done) return;
-    (void)hipFuncSetAttribute((const void*)attn_bwd32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<1>());
-    (void)hipFuncSetAttribute((const void*)attn_bwd32_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<7>());
-    done = true;
+int attention32_init(int device) {
+    static bool done[64] = {};
+    if (device < 0 || device >= 64) return -1;
+    if (done[device]) return 0;
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<1>());
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)attn_bwd32_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<7>());
+    if (e != hipSuccess) return (int)e;
+    done[device] = true;
+    return 0;
 }
 
-int k_attention32_fwd(const bf16* qkv, bf16* ctx, float* lse2, int B, int T, int H, int D, hipStream_t s) {
+int k_attention32_fwd(const h16* qkv, h16* ctx, float* lse2, int B, int T, int H, int D, hipStream_t s) {
     ProfScope prof_("attn_fwd32_kernel", 4.0 * B * H * (double)T * T * HD, (double)B * T * D * 8.0, s);
     const float sl = 0.125f * 1.4426950408889634f;
     if (T <= 32) hipLaunchKernelGGL((attn_fwd32_kernel<1>), dim3(B * H), dim3(64 * FWD_WAVES), 0, s, qkv, ctx, lse2, T, H, D, sl);
@@ -453,7 +457,7 @@ int k_attention32_fwd(const bf16* qkv, bf16* ctx, float* lse2, int B, int T, int
     return 0;
 }
 
-int k_attention32_bwd(const bf16* qkv, const bf16* ctx, const bf16* dctx, const float* lse2, bf16* dqkv, int B, int T,
+int k_attention32_bwd(const h16* qkv, const h16* ctx, const h16* dctx, const float* lse2, h16* dqkv, int B, int T,
                       int H, int D, hipStream_t s) {
     ProfScope prof_("attn_bwd32_kernel", 10.0 * B * H * (double)T * T * HD, (double)B * T * D * 16.0, s);
     if (T <= 32) launch_bwd<1>(qkv, ctx, dctx, lse2, dqkv, B, T, H, D, s);

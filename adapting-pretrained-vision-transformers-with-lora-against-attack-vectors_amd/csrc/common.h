@@ -1,34 +1,37 @@
-// Shared device/host helpers for the gfx950 kernels (wave64, MFMA 16x16x32 bf16).
+// Shared device/host helpers for the gfx950 kernels (wave64, fp16 MFMA 16x16x32 / 32x32x16, fp32 accumulation).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef __bf16 bf16;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16;
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
-__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
-__device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }   // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ float h2f(h16 v) { return (float)v; }
+__device__ __forceinline__ h16 f2h(float v) { return (h16)v; }   // RNE (v_cvt_pk_f16_f32); overflows to inf above 65504
+// saturating form for the scaled gradients of the backward elementwise kernels (HBM-bound: the clamp is free there):
+// a gradient that outgrows fp16 saturates instead of turning the whole image's gradient into inf / NaN
+__device__ __forceinline__ h16 f2h_sat(float v) { return (h16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
 
-__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+__device__ __forceinline__ f32x4 mfma16(h16x8 a, h16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
 // Transposed LDS read: within each 16-lane group, lane 4q+p supplies the address of row q,
 // columns 4p..4p+3 of a 4x16 block of 16-bit elements; lane i receives column i of the 4 rows.
 // EXEC must be all ones; every address 8-byte aligned.
-__device__ __forceinline__ bf16x4 lds_read_tr16(const void* lds_addr) {
+__device__ __forceinline__ h16x4 lds_read_tr16(const void* lds_addr) {
     s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_addr));
-    return __builtin_bit_cast(bf16x4, t);
+    return __builtin_bit_cast(h16x4, t);
 }
 
-__device__ __forceinline__ bf16x8 cat4(bf16x4 lo, bf16x4 hi) {
+__device__ __forceinline__ h16x8 cat4(h16x4 lo, h16x4 hi) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 

@@ -8,10 +8,10 @@
 namespace {
 
 // ---------------------------------------------------------------------------------
-// K1+K2 gather: pixels [B,3,S,S] f32 -> patches [B*NP (padded), 3*P*P] bf16, (x-mean)/std fused
+// K1+K2 gather: pixels [B,3,S,S] f32 -> patches [B*NP (padded), 3*P*P] h16, (x-mean)/std fused
 // (whitebox_attacks.py:26 feeds (perturbed-mean)/std to the Conv2d patch projection).
 // ---------------------------------------------------------------------------------
-__global__ void patch_gather_kernel(const float* __restrict__ x, bf16* __restrict__ out, int B, int S,
+__global__ void patch_gather_kernel(const float* __restrict__ x, h16* __restrict__ out, int B, int S,
                                     int P, int G, int normalise, float m0, float m1, float m2,
                                     float is0, float is1, float is2) {
     const int K = 3 * P * P;
@@ -29,10 +29,10 @@ __global__ void patch_gather_kernel(const float* __restrict__ x, bf16* __restric
         const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
         float mean = 0.f, is = 1.f;
         if (normalise) { mean = c == 0 ? m0 : (c == 1 ? m1 : m2); is = c == 0 ? is0 : (c == 1 ? is1 : is2); }
-        bf16x8 o;
+        h16x8 o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { o[i] = f2bf((v0[i] - mean) * is); o[4 + i] = f2bf((v1[i] - mean) * is); }
-        *(bf16x8*)(out + m * K + col) = o;
+        for (int i = 0; i < 4; ++i) { o[i] = f2h((v0[i] - mean) * is); o[4 + i] = f2h((v1[i] - mean) * is); }
+        *(h16x8*)(out + m * K + col) = o;
     }
 }
 
@@ -49,15 +49,15 @@ __global__ void cls_rows_kernel(float* __restrict__ x, const float* __restrict__
 // LayerNorm forward: one wave per row, two-pass statistics in registers.
 // ---------------------------------------------------------------------------------
 // LoRA down-projection of ONE row fused into the kernel that produces the row (saves the separate skinny GEMM's
-// pass over the activation): out[j] = sum_c v[c] * P[j][c] for the 8*NG rows of P (bf16 [>= 8*NG, D], zero rows
-// past r * modules), written as a full 64-column bf16 row (zeros past 8*NG).  v = this lane's 4*NV values of the
-// row (the bf16 values the GEMM this replaces would read), columns (lane + 64 i)*4 + k.
+// pass over the activation): out[j] = sum_c v[c] * P[j][c] for the 8*NG rows of P (h16 [>= 8*NG, D], zero rows
+// past r * modules), written as a full 64-column h16 row (zeros past 8*NG).  v = this lane's 4*NV values of the
+// row (the h16 values the GEMM this replaces would read), columns (lane + 64 i)*4 + k.
 // Reduction: halving butterfly (4 + 2 + 1 exchanges leave lane L with column (L>>3)&7) + 3 xor steps.
 template <int NV, int NG>
-struct LoraDownP { bf16x4 p[NG][NV][8]; };
+struct LoraDownP { h16x4 p[NG][NV][8]; };
 // this lane's slice of P, fetched EARLY (before the row's own loads are consumed) so that its L2 latency hides
 template <int NV, int NG>
-__device__ __forceinline__ void lora_down_load(LoraDownP<NV, NG>& r, int nv, int lane, const bf16* __restrict__ P, int D) {
+__device__ __forceinline__ void lora_down_load(LoraDownP<NV, NG>& r, int nv, int lane, const h16* __restrict__ P, int D) {
 #pragma unroll
     for (int gq = 0; gq < NG; ++gq)
 #pragma unroll
@@ -65,13 +65,13 @@ __device__ __forceinline__ void lora_down_load(LoraDownP<NV, NG>& r, int nv, int
             const int c = lane + i * 64;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                r.p[gq][i][j] = c < nv ? *(const bf16x4*)(P + (size_t)(gq * 8 + j) * D + c * 4) : bf16x4{0, 0, 0, 0};
+                r.p[gq][i][j] = c < nv ? *(const h16x4*)(P + (size_t)(gq * 8 + j) * D + c * 4) : h16x4{0, 0, 0, 0};
         }
 }
 template <int NV, int NG>
-__device__ __forceinline__ void lora_down_row(const bf16x4 (&v)[NV], const LoraDownP<NV, NG>& r, int nv, int lane,
-                                              bf16* __restrict__ out_row) {
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lora_down_row(const h16x4 (&v)[NV], const LoraDownP<NV, NG>& r, int nv, int lane,
+                                              h16* __restrict__ out_row) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     float outv = 0.f;
 #pragma unroll
     for (int gq = 0; gq < NG; ++gq) {
@@ -82,13 +82,13 @@ __device__ __forceinline__ void lora_down_row(const bf16x4 (&v)[NV], const LoraD
         for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
             if (c < nv) {
-                const bf2 vlo = {v[i][0], v[i][1]}, vhi = {v[i][2], v[i][3]};
+                const h2 vlo = {v[i][0], v[i][1]}, vhi = {v[i][2], v[i][3]};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const bf16x4 p = r.p[gq][i][j];
-                    const bf2 plo = {p[0], p[1]}, phi = {p[2], p[3]};
-                    acc[j] = __builtin_amdgcn_fdot2_f32_bf16(vlo, plo, acc[j], false);     // v_dot2c_f32_bf16: no conversions
-                    acc[j] = __builtin_amdgcn_fdot2_f32_bf16(vhi, phi, acc[j], false);
+                    const h16x4 p = r.p[gq][i][j];
+                    const h2 plo = {p[0], p[1]}, phi = {p[2], p[3]};
+                    acc[j] = __builtin_amdgcn_fdot2(vlo, plo, acc[j], false);     // v_dot2c_f32_f16: no conversions
+                    acc[j] = __builtin_amdgcn_fdot2(vhi, phi, acc[j], false);
                 }
             }
         }
@@ -105,16 +105,16 @@ __device__ __forceinline__ void lora_down_row(const bf16x4 (&v)[NV], const LoraD
         const float routed = __shfl(a1, (lane & 7) << 3, 64);       // column j sits in lanes 8j .. 8j+7
         if ((lane >> 3) == gq) outv = routed;
     }
-    out_row[lane] = f2bf(lane < 8 * NG ? outv : 0.f);
+    out_row[lane] = f2h(lane < 8 * NG ? outv : 0.f);
 }
 
 template <int NV, int NG>
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, bf16* __restrict__ h,
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, h16* __restrict__ h,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            int M, int D, float eps, const bf16* __restrict__ delta,
-                                                            float* __restrict__ xout, const bf16* __restrict__ P,
-                                                            bf16* __restrict__ t) {
+                                                            int M, int D, float eps, const h16* __restrict__ delta,
+                                                            float* __restrict__ xout, const h16* __restrict__ P,
+                                                            h16* __restrict__ t) {
     const int lane = threadIdx.x & 63;
     const int nv = D >> 2;
     LoraDownP<NV, NG ? NG : 1> pr;                  // fused t = h Ad^T of the projection that reads h next (see layernorm_bwd_kernel)
@@ -136,10 +136,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             const int c = lane + i * 64;
             v[i] = c < nv ? *(const f32x4*)(xr + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
             if (delta && c < nv) {
-                // residual add fused in: x_out = x + delta (the bf16 output of the projection before it)
-                const bf16x4 dl = *(const bf16x4*)(delta + (int64_t)row * D + c * 4);
+                // residual add fused in: x_out = x + delta (the h16 output of the projection before it)
+                const h16x4 dl = *(const h16x4*)(delta + (int64_t)row * D + c * 4);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[i][k] += bf2f(dl[k]);
+                for (int k = 0; k < 4; ++k) v[i][k] += h2f(dl[k]);
                 *(f32x4*)(xout + (int64_t)row * D + c * 4) = v[i];
             }
             s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
@@ -157,17 +157,17 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         }
         const float rstd = rsqrtf(wave_sum(q) / D + eps);
         if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
-        bf16* hr = h + (int64_t)row * D;
-        bf16x4 vb[NV];
+        h16* hr = h + (int64_t)row * D;
+        h16x4 vb[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
             if (c < nv) {
                 const f32x4 g = gam[i], b = bet[i];
-                bf16x4 o;
+                h16x4 o;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = f2bf((v[i][k] - mean) * rstd * g[k] + b[k]);
-                *(bf16x4*)(hr + c * 4) = o;
+                for (int k = 0; k < 4; ++k) o[k] = f2h((v[i][k] - mean) * rstd * g[k] + b[k]);
+                *(h16x4*)(hr + c * 4) = o;
                 vb[i] = o;
             }
         }
@@ -177,13 +177,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 
 // LayerNorm backward fused with the residual-gradient add:
 //   dx = dres + rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dh * gamma
-// writes dx as f32 (residual-gradient stream) and as bf16 (A operand of the next dgrad GEMM).
+// writes dx as f32 (residual-gradient stream) and as h16 (A operand of the next dgrad GEMM).
 template <int NV, int NG>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restrict__ dh, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const h16* __restrict__ dh, const float* __restrict__ x,
                                                             const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                             const float* __restrict__ gamma, const float* __restrict__ dres,
-                                                            float* __restrict__ dx, bf16* __restrict__ dx_bf, int M, int D,
-                                                            const bf16* __restrict__ P, bf16* __restrict__ u) {
+                                                            float* __restrict__ dx, h16* __restrict__ dx_h, int M, int D,
+                                                            const h16* __restrict__ P, h16* __restrict__ u) {
     const int lane = threadIdx.x & 63;
     const int nv = D >> 2;
     // with the fused projection a wave keeps its slice of P in registers and walks rows (grid-stride): P is read
@@ -201,12 +201,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
         g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         xh[i] = g[i];
         if (c < nv) {
-            const bf16x4 d = *(const bf16x4*)(dh + off + c * 4);
+            const h16x4 d = *(const h16x4*)(dh + off + c * 4);
             const f32x4 xv = *(const f32x4*)(x + off + c * 4);
             const f32x4 gm = *(const f32x4*)(gamma + c * 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                g[i][k] = bf2f(d[k]) * gm[k];
+                g[i][k] = h2f(d[k]) * gm[k];
                 xh[i][k] = (xv[k] - mean) * rstd;
                 s1 += g[i][k];
                 s2 += g[i][k] * xh[i][k];
@@ -214,24 +214,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
         }
     }
     const float c1 = wave_sum(s1) / D, c2 = wave_sum(s2) / D;
-    bf16x4 vb[NV];
+    h16x4 vb[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
             const f32x4 r = *(const f32x4*)(dres + off + c * 4);     // (requesting it with the row's first loads costs a wave per SIMD: +30 %)
-            f32x4 o; bf16x4 ob;
+            f32x4 o; h16x4 ob;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 o[k] = r[k] + rstd * (g[i][k] - c1 - xh[i][k] * c2);
-                ob[k] = f2bf(o[k]);
+                ob[k] = f2h_sat(o[k]);
             }
             *(f32x4*)(dx + off + c * 4) = o;
-            *(bf16x4*)(dx_bf + off + c * 4) = ob;
+            *(h16x4*)(dx_h + off + c * 4) = ob;
             vb[i] = ob;                                              // the row as the next dgrad GEMM reads it
         }
     }
-    // u = dx_bf B of the projection whose dgrad consumes dx_bf next (linear_dgrad skips its down GEMM)
+    // u = dx_h B of the projection whose dgrad consumes dx_h next (linear_dgrad skips its down GEMM)
     if constexpr (NG > 0) lora_down_row<NV, NG>(vb, pr, nv, lane, u + (int64_t)row * 64);
     }
 }
@@ -287,10 +287,17 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 // one wave per image (4 per block) writes the per-image loss; a second tiny launch sums them in a
 // fixed order (bitwise reproducible loss).
 __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                                      int B, int C, float* __restrict__ dlogits, float* __restrict__ loss_img) {
+                                                      int B, int C, float* __restrict__ dlogits, float* __restrict__ loss_img,
+                                                      int* __restrict__ err) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
+    const int64_t yl = labels[b];
+    if (yl < 0 || yl >= C) {               // refuse loudly: NaN loss for this image + the error word the next API call reports
+        for (int c = lane; c < C; c += 64) dlogits[(int64_t)b * C + c] = __builtin_nanf("");
+        if (lane == 0) { loss_img[b] = __builtin_nanf(""); if (err) *err = 1; }
+        return;
+    }
     const float* lr = logits + (int64_t)b * C;
     float mx = -INFINITY;
     for (int c = lane; c < C; c += 64) mx = fmaxf(mx, lr[c]);
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
     float se = 0.f;
     for (int c = lane; c < C; c += 64) se += expf(lr[c] - mx);
     se = wave_sum(se);
-    const int y = (int)labels[b];
+    const int y = (int)yl;
     const float lse = mx + logf(se);
     for (int c = lane; c < C; c += 64)
         dlogits[(int64_t)b * C + c] = (expf(lr[c] - lse) - (c == y ? 1.f : 0.f)) / B;
@@ -316,19 +323,21 @@ __global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict_
 
 // head backward: d(xf) = dlogits * Wc ; LN backward on the CLS row; writes the CLS row of the
 // residual-gradient stream (all other rows of that stream are zero: memset by the driver).
-__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ Wc,
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ gscale,
+                                                       const float* __restrict__ Wc,
                                                        const float* __restrict__ gamma, const float* __restrict__ xhat,
                                                        const float* __restrict__ rstd_in, int T, int D, int C,
-                                                       float* __restrict__ dx, bf16* __restrict__ dx_bf) {
+                                                       float* __restrict__ dx, h16* __restrict__ dx_h) {
     extern __shared__ float sm[];
     float* g = sm;           // [D]
     float* red = sm + D;
     const int b = blockIdx.x;
+    const float gs = gscale ? gscale[b] : 1.f;
     float s1 = 0.f, s2 = 0.f;
     for (int d = threadIdx.x; d < D; d += 256) {
         float a = 0.f;
         for (int c = 0; c < C; ++c) a += dlogits[(int64_t)b * C + c] * Wc[(int64_t)c * D + d];
-        a *= gamma[d];
+        a *= gamma[d] * gs;
         g[d] = a;
         s1 += a;
         s2 += a * xhat[(int64_t)b * D + d];
@@ -339,7 +348,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     for (int d = threadIdx.x; d < D; d += 256) {
         const float o = rstd * (g[d] - c1 - xhat[(int64_t)b * D + d] * c2);
         dx[(int64_t)b * T * D + d] = o;
-        dx_bf[(int64_t)b * T * D + d] = f2bf(o);
+        if (dx_h) dx_h[(int64_t)b * T * D + d] = f2h_sat(o);
     }
 }
 
@@ -406,11 +415,11 @@ __global__ void pgd_init_kernel(float* __restrict__ adv, const float* __restrict
     }
 }
 
-__global__ void fill_random_bf16_kernel(bf16* __restrict__ dst, size_t n, uint64_t seed) {
+__global__ void fill_random_h16_kernel(h16* __restrict__ dst, size_t n, uint64_t seed) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint64_t r = mix64(seed * 0xD1342543DE82EF95ull + i);
-        dst[i] = f2bf((float)(r >> 40) * (2.0f / 16777216.0f) - 1.0f);
+        dst[i] = f2h((float)(r >> 40) * (2.0f / 16777216.0f) - 1.0f);
     }
 }
 
@@ -457,16 +466,16 @@ __global__ void channel_affine_kernel(float* __restrict__ dst, const float* __re
 // ---------------------------------------------------------------------------------
 // packers
 // ---------------------------------------------------------------------------------
-// dst[r*ldd + coff + c] = bf16(scale * src[r*cols + c])
-__global__ void pack_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int rows, int cols, int ldd,
+// dst[r*ldd + coff + c] = h16(scale * src[r*cols + c])
+__global__ void pack_h16_kernel(const float* __restrict__ src, h16* __restrict__ dst, int rows, int cols, int ldd,
                                  int coff, float scale) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= (int64_t)rows * cols) return;
     const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
-    dst[(int64_t)r * ldd + coff + c] = f2bf(scale * src[i]);
+    dst[(int64_t)r * ldd + coff + c] = f2h(scale * src[i]);
 }
-// dst[c*ldd + roff + r] = bf16(scale * src[r*cols + c])   (transpose)
-__global__ void pack_bf16_t_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int rows, int cols, int ldd,
+// dst[c*ldd + roff + r] = h16(scale * src[r*cols + c])   (transpose)
+__global__ void pack_h16_t_kernel(const float* __restrict__ src, h16* __restrict__ dst, int rows, int cols, int ldd,
                                    int roff, float scale) {
     __shared__ float tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
@@ -478,19 +487,19 @@ __global__ void pack_bf16_t_kernel(const float* __restrict__ src, bf16* __restri
     __syncthreads();
     for (int k = ty; k < 32; k += 8) {
         const int c = bx + k, r = by + tx;
-        if (r < rows && c < cols) dst[(int64_t)c * ldd + roff + r] = f2bf(scale * tile[tx][k]);
+        if (r < rows && c < cols) dst[(int64_t)c * ldd + roff + r] = f2h(scale * tile[tx][k]);
     }
 }
-// W'[o][k] = bf16(W[o][k] + s * sum_j B[o][j] A[j][k])  (merge_and_unload), optionally transposed
+// W'[o][k] = h16(W[o][k] + s * sum_j B[o][j] A[j][k])  (merge_and_unload), optionally transposed
 __global__ void merge_lora_kernel(const float* __restrict__ W, const float* __restrict__ A, const float* __restrict__ Bm,
-                                  int out, int in, int r, float s, bf16* __restrict__ dst, int ldd, int roff,
-                                  bf16* __restrict__ dstT, int lddT, int coffT) {
+                                  int out, int in, int r, float s, h16* __restrict__ dst, int ldd, int roff,
+                                  h16* __restrict__ dstT, int lddT, int coffT) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= (int64_t)out * in) return;
     const int o = (int)(i / in), k = (int)(i - (int64_t)o * in);
     float a = 0.f;
     for (int j = 0; j < r; ++j) a += Bm[(int64_t)o * r + j] * A[(int64_t)j * in + k];
-    const bf16 v = f2bf(W[i] + s * a);
+    const h16 v = f2h(W[i] + s * a);
     dst[(int64_t)(roff + o) * ldd + k] = v;
     dstT[(int64_t)k * lddT + coffT + o] = v;
 }
@@ -521,7 +530,7 @@ static inline int nblk(int64_t n, int t, int cap = 1 << 20) {
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
-void k_patch_gather(const float* x, bf16* out, int B, int S, int P, int normalise, const float* mean,
+void k_patch_gather(const float* x, h16* out, int B, int S, int P, int normalise, const float* mean,
                     const float* std, hipStream_t s) {
     ProfScope prof_("patch_gather_kernel", 0.0, (double)B * 3 * S * S * 6.0, s);
     const int G = S / P;
@@ -533,15 +542,15 @@ void k_cls_rows(float* x, const float* cls, const float* pos, int B, int T, int 
     hipLaunchKernelGGL(cls_rows_kernel, dim3(nblk((int64_t)B * D, 256)), dim3(256), 0, s, x, cls, pos, B, T, D);
 }
 template <int NV>
-static void launch_ln_fwd(dim3 grid, hipStream_t s, const float* x, bf16* h, float* mean, float* rstd, const float* g,
-                          const float* b, int M, int D, float eps, const bf16* delta, float* xout, const bf16* P, int ng, bf16* t) {
+static void launch_ln_fwd(dim3 grid, hipStream_t s, const float* x, h16* h, float* mean, float* rstd, const float* g,
+                          const float* b, int M, int D, float eps, const h16* delta, float* xout, const h16* P, int ng, h16* t) {
     if (ng == 1) hipLaunchKernelGGL((layernorm_fwd_kernel<NV, 1>), grid, dim3(256), 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, t);
     else if (ng == 2) hipLaunchKernelGGL((layernorm_fwd_kernel<NV, 2>), grid, dim3(256), 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, t);
     else if (ng == 3) hipLaunchKernelGGL((layernorm_fwd_kernel<NV, 3>), grid, dim3(256), 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, t);
     else hipLaunchKernelGGL((layernorm_fwd_kernel<NV, 0>), grid, dim3(256), 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, t);
 }
-void k_layernorm_fwd(const float* x, bf16* h, float* mean, float* rstd, const float* g, const float* b, int M, int D,
-                     float eps, const bf16* delta, float* xout, const bf16* P, int ng, bf16* t, hipStream_t s) {
+void k_layernorm_fwd(const float* x, h16* h, float* mean, float* rstd, const float* g, const float* b, int M, int D,
+                     float eps, const h16* delta, float* xout, const h16* P, int ng, h16* t, hipStream_t s) {
     ProfScope prof_("layernorm_fwd_kernel", 0.0, (double)M * D * (delta ? (h ? 12.0 : 10.0) : 6.0), s);
     const int nv = (D / 4 + 63) / 64;
     if (!P || !t || !h || ng < 0 || ng > 3) ng = 0;
@@ -555,24 +564,24 @@ void k_layernorm_fwd(const float* x, bf16* h, float* mean, float* rstd, const fl
     }
 }
 template <int NV>
-static void launch_ln_bwd(dim3 grid, hipStream_t s, const bf16* dh, const float* x, const float* mean, const float* rstd,
-                          const float* g, const float* dres, float* dx, bf16* dx_bf, int M, int D, const bf16* P, int ng, bf16* u) {
-    if (ng == 1) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 1>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D, P, u);
-    else if (ng == 2) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 2>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D, P, u);
-    else hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 0>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D, P, u);
+static void launch_ln_bwd(dim3 grid, hipStream_t s, const h16* dh, const float* x, const float* mean, const float* rstd,
+                          const float* g, const float* dres, float* dx, h16* dx_h, int M, int D, const h16* P, int ng, h16* u) {
+    if (ng == 1) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 1>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u);
+    else if (ng == 2) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 2>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u);
+    else hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 0>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u);
 }
-void k_layernorm_bwd(const bf16* dh, const float* x, const float* mean, const float* rstd, const float* g,
-                     const float* dres, float* dx, bf16* dx_bf, int M, int D, const bf16* P, int ng, bf16* u, hipStream_t s) {
+void k_layernorm_bwd(const h16* dh, const float* x, const float* mean, const float* rstd, const float* g,
+                     const float* dres, float* dx, h16* dx_h, int M, int D, const h16* P, int ng, h16* u, hipStream_t s) {
     ProfScope prof_("layernorm_bwd_kernel", 0.0, (double)M * D * 16.0, s);
     const int nv = (D / 4 + 63) / 64;
     if (!P || !u || ng < 0 || ng > 2) ng = 0;
     dim3 grid((M + 3) / 4);
     if (ng && grid.x > 1024) grid.x = 1024;          // 4 resident blocks per CU walk the rows
     switch (nv) {
-        case 1: launch_ln_bwd<1>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D, P, ng, u); break;
-        case 2: launch_ln_bwd<2>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D, P, ng, u); break;
-        case 3: launch_ln_bwd<3>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D, P, ng, u); break;
-        default: launch_ln_bwd<4>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_bf, M, D, P, ng, u); break;
+        case 1: launch_ln_bwd<1>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, ng, u); break;
+        case 2: launch_ln_bwd<2>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, ng, u); break;
+        case 3: launch_ln_bwd<3>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, ng, u); break;
+        default: launch_ln_bwd<4>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, ng, u); break;
     }
 }
 void k_head_fwd(const float* x, int B, int T, int D, int C, float eps, const float* g, const float* b, const float* Wc,
@@ -582,15 +591,51 @@ void k_head_fwd(const float* x, int B, int T, int D, int C, float eps, const flo
                        xhat, xf, rstd, logits);
 }
 void k_ce_loss(const float* logits, const int64_t* labels, int B, int C, float* dlogits, float* loss_img, float* loss,
-               hipStream_t s) {
-    hipLaunchKernelGGL(ce_loss_kernel, dim3((B + 3) / 4), dim3(256), 0, s, logits, labels, B, C, dlogits, loss_img);
+               int* err, hipStream_t s) {
+    hipLaunchKernelGGL(ce_loss_kernel, dim3((B + 3) / 4), dim3(256), 0, s, logits, labels, B, C, dlogits, loss_img, err);
     hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, s, loss_img, B, loss);
 }
-void k_head_bwd(const float* dlogits, const float* Wc, const float* g, const float* xhat, const float* rstd, int B,
-                int T, int D, int C, float* dx, bf16* dx_bf, hipStream_t s) {
+void k_head_bwd(const float* dlogits, const float* gscale, const float* Wc, const float* g, const float* xhat,
+                const float* rstd, int B, int T, int D, int C, float* dx, h16* dx_h, hipStream_t s) {
     ProfScope prof_("head_bwd_kernel", 0.0, (double)B * D * 6.0, s);
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), (D + 4) * sizeof(float), s, dlogits, Wc, g, xhat, rstd, T,
-                       D, C, dx, dx_bf);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), (D + 4) * sizeof(float), s, dlogits, gscale, Wc, g, xhat, rstd,
+                       T, D, C, dx, dx_h);
+}
+
+namespace {
+// one block: per-image (or whole-batch) max |dlogits| -> power-of-two scale that puts it in [2^9, 2^10)
+__global__ __launch_bounds__(256) void grad_scale_kernel(const float* __restrict__ dlogits, int B, int C, int uniform,
+                                                         float* __restrict__ gscale, float* __restrict__ inv_gscale) {
+    __shared__ float red[4];
+    auto scale_of = [](float mx) -> float {
+        if (!(mx > 0.f) || !(mx < INFINITY)) return 1.f;          // all-zero or non-finite row: leave it alone
+        int e;
+        (void)frexpf(mx, &e);                                     // mx = f * 2^e, f in [0.5, 1)
+        e = 10 - e;
+        e = e < -60 ? -60 : (e > 60 ? 60 : e);
+        return ldexpf(1.f, e);
+    };
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (uniform) {
+        float mx = 0.f;
+        for (int i = threadIdx.x; i < B * C; i += 256) mx = fmaxf(mx, fabsf(dlogits[i]));
+        mx = wave_max(mx);
+        if (lane == 0) red[w] = mx;
+        __syncthreads();
+        const float sc = scale_of(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+        for (int b = threadIdx.x; b < B; b += 256) { gscale[b] = sc; inv_gscale[b] = 1.f / sc; }
+        return;
+    }
+    for (int b = w; b < B; b += 4) {
+        float mx = 0.f;
+        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, fabsf(dlogits[(int64_t)b * C + c]));
+        mx = wave_max(mx);
+        if (lane == 0) { const float sc = scale_of(mx); gscale[b] = sc; inv_gscale[b] = 1.f / sc; }
+    }
+}
+}  // namespace
+void k_grad_scale(const float* dlogits, int B, int C, int uniform, float* gscale, float* inv_gscale, hipStream_t s) {
+    hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(256), 0, s, dlogits, B, C, uniform, gscale, inv_gscale);
 }
 void k_classifier_grad(const float* dlogits, const float* xf, int B, int D, int C, float* dW, float* db, hipStream_t s) {
     hipLaunchKernelGGL(classifier_grad_kernel, dim3(nblk((int64_t)C * D, 256)), dim3(256), 0, s, dlogits, xf, B, D, C,
@@ -620,23 +665,23 @@ void k_channel_affine(float* dst, const float* src, const float* scale, const fl
     hipLaunchKernelGGL(channel_affine_kernel, dim3(nblk(n, 256, 4096)), dim3(256), 0, s, dst, src, scale[0], scale[1],
                        scale[2], shift[0], shift[1], shift[2], hw, n);
 }
-void k_fill_random_bf16(bf16* dst, size_t n, uint64_t seed, hipStream_t s) {
-    hipLaunchKernelGGL(fill_random_bf16_kernel, dim3(4096), dim3(256), 0, s, dst, n, seed);
+void k_fill_random_h16(h16* dst, size_t n, uint64_t seed, hipStream_t s) {
+    hipLaunchKernelGGL(fill_random_h16_kernel, dim3(4096), dim3(256), 0, s, dst, n, seed);
 }
 void k_quantize(const float* img, uint8_t* out, int B, int C, int H, int W, hipStream_t s) {
     const int64_t n = (int64_t)B * C * H * W;
     hipLaunchKernelGGL(quantize_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, img, out, B, C, H, W);
 }
-void k_pack_bf16(const float* src, bf16* dst, int rows, int cols, int ldd, int coff, float scale, hipStream_t s) {
-    hipLaunchKernelGGL(pack_bf16_kernel, dim3(nblk((int64_t)rows * cols, 256)), dim3(256), 0, s, src, dst, rows, cols,
+void k_pack_h16(const float* src, h16* dst, int rows, int cols, int ldd, int coff, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(pack_h16_kernel, dim3(nblk((int64_t)rows * cols, 256)), dim3(256), 0, s, src, dst, rows, cols,
                        ldd, coff, scale);
 }
-void k_pack_bf16_t(const float* src, bf16* dst, int rows, int cols, int ldd, int roff, float scale, hipStream_t s) {
+void k_pack_h16_t(const float* src, h16* dst, int rows, int cols, int ldd, int roff, float scale, hipStream_t s) {
     dim3 grid((cols + 31) / 32, (rows + 31) / 32);
-    hipLaunchKernelGGL(pack_bf16_t_kernel, grid, dim3(256), 0, s, src, dst, rows, cols, ldd, roff, scale);
+    hipLaunchKernelGGL(pack_h16_t_kernel, grid, dim3(256), 0, s, src, dst, rows, cols, ldd, roff, scale);
 }
-void k_merge_lora(const float* W, const float* A, const float* B, int out, int in, int r, float sc, bf16* dst, int ldd,
-                  int roff, bf16* dstT, int lddT, int coffT, hipStream_t s) {
+void k_merge_lora(const float* W, const float* A, const float* B, int out, int in, int r, float sc, h16* dst, int ldd,
+                  int roff, h16* dstT, int lddT, int coffT, hipStream_t s) {
     hipLaunchKernelGGL(merge_lora_kernel, dim3(nblk((int64_t)out * in, 256)), dim3(256), 0, s, W, A, B, out, in, r, sc,
                        dst, ldd, roff, dstT, lddT, coffT);
 }
@@ -645,15 +690,15 @@ void k_merge_lora(const float* W, const float* A, const float* B, int out, int i
 // LoRA dropout (train mode): xd = x * mask/(1-p), mask = drop_scale(seed, stream, m*cols + c)
 // ---------------------------------------------------------------------------------
 namespace {
-__global__ void dropout_kernel(const bf16* __restrict__ x, bf16* __restrict__ xd, int64_t n8, uint64_t seed,
+__global__ void dropout_kernel(const h16* __restrict__ x, h16* __restrict__ xd, int64_t n8, uint64_t seed,
                                uint32_t stream, float p, float inv_keep) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += stride) {
-        const bf16x8 v = *(const bf16x8*)(x + i * 8);
-        bf16x8 o;
+        const h16x8 v = *(const h16x8*)(x + i * 8);
+        h16x8 o;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = f2bf(bf2f(v[k]) * drop_scale(seed, stream, (uint64_t)(i * 8 + k), p, inv_keep));
-        *(bf16x8*)(xd + i * 8) = o;
+        for (int k = 0; k < 8; ++k) o[k] = f2h(h2f(v[k]) * drop_scale(seed, stream, (uint64_t)(i * 8 + k), p, inv_keep));
+        *(h16x8*)(xd + i * 8) = o;
     }
 }
 __global__ void dropout_mask_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint32_t stream, float p,
@@ -664,7 +709,7 @@ __global__ void dropout_mask_kernel(float* __restrict__ out, int64_t n, uint64_t
 }
 }  // namespace
 
-void k_dropout(const bf16* x, bf16* xd, int64_t n, uint64_t seed, uint32_t stream, float p, hipStream_t s) {
+void k_dropout(const h16* x, h16* xd, int64_t n, uint64_t seed, uint32_t stream, float p, hipStream_t s) {
     ProfScope prof_("dropout_kernel", 0.0, (double)n * 4.0, s);
     hipLaunchKernelGGL(dropout_kernel, dim3(nblk(n / 8, 256, 4096)), dim3(256), 0, s, x, xd, n / 8, seed, stream, p,
                        1.f / (1.f - p));

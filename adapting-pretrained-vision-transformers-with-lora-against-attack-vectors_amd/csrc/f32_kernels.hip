@@ -1,0 +1,490 @@
+// Kernels of the fp32 PARITY mode (vl_config.precision = VL_PREC_F32): every operand, activation and
+// gradient is fp32, matrix products run on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32: bit-for-bit a
+// k-ordered fmaf chain).  This mode exists to be compared with the reference's fp32 CPU path at 1e-3
+// (whitebox_attacks.py:22-38, train_loras.py:310-315 run in fp32, no autocast); it is written for
+// clarity, not for the roofline -- the fp16-operand kernels (gemm256.hip, attention32.hip) are the
+// performance path.
+#include <cstdio>
+
+#include "f32_kernels.h"
+#include "prof.h"
+
+namespace {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// C[M,N] = alpha * A[M,K] * op(W) + bias + R      64 x 64 x 16 tiles, 4 waves (2 x 2), 16x16x4 f32 MFMA
+// with the operands swapped (D[n][m]) so that a lane owns 4 consecutive output columns.
+// ---------------------------------------------------------------------------------------------
+constexpr int FBM = 64, FBN = 64, FBK = 16, FLD = FBK + 1;
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32 p) {
+    __shared__ float sA[FBM * FLD];
+    __shared__ float sW[FBN * FLD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int m0 = blockIdx.y * FBM, n0 = blockIdx.x * FBN;
+    f32x4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // non-transposed operand: thread -> (row = tid / 4, 4 consecutive k); transposed: (k = tid / 16, 4 consecutive rows)
+    const int r_nt = tid >> 2, k_nt = (tid & 3) * 4;
+    const int k_tr = tid >> 4, r_tr = (tid & 15) * 4;
+    int64_t arow = -1;                       // source row of the A operand (non-transposed form)
+    if (!p.transA) {
+        int m = m0 + r_nt;
+        if (m < p.M) {
+            if (p.a_gather) m = m + m / p.patches + 1;     // GEMM row b*patches + pi reads token row b*tokens + 1 + pi
+            arow = m;
+        }
+    }
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < p.K; k0 += FBK) {
+        f32x4_t av = zero, wv = zero;
+        if (!p.transA) {
+            if (arow >= 0 && k0 + k_nt < p.K) av = *(const f32x4_t*)(p.A + arow * p.lda + k0 + k_nt);
+        } else {
+            if (k0 + k_tr < p.K && m0 + r_tr < p.M) av = *(const f32x4_t*)(p.A + (int64_t)(k0 + k_tr) * p.lda + m0 + r_tr);
+        }
+        if (!p.transW) {
+            if (n0 + r_nt < p.N && k0 + k_nt < p.K) wv = *(const f32x4_t*)(p.W + (int64_t)(n0 + r_nt) * p.ldw + k0 + k_nt);
+        } else {
+            if (k0 + k_tr < p.K && n0 + r_tr < p.N) wv = *(const f32x4_t*)(p.W + (int64_t)(k0 + k_tr) * p.ldw + n0 + r_tr);
+        }
+        __syncthreads();                                 // the previous step's fragment reads are done
+        if (!p.transA) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sA[r_nt * FLD + k_nt + i] = av[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sA[(r_tr + i) * FLD + k_tr] = av[i];
+        }
+        if (!p.transW) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sW[r_nt * FLD + k_nt + i] = wv[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sW[(r_tr + i) * FLD + k_tr] = wv[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float af[2], wf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = sA[(wm * 32 + i * 16 + (lane & 15)) * FLD + kk * 4 + (lane >> 4)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wf[j] = sW[(wn * 32 + j * 16 + (lane & 15)) * FLD + kk * 4 + (lane >> 4)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j], af[i], acc[i][j], 0, 0, 0);   // D[n][m]
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 32 + i * 16 + (lane & 15);
+        if (m >= p.Mstore) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 32 + j * 16 + 4 * (lane >> 4);
+            if (n >= p.N) continue;                      // N is a multiple of 4: a lane's 4 columns are in or out together
+            f32x4_t v = acc[i][j] * p.alpha;
+            if (p.bias) v += *(const f32x4_t*)(p.bias + n);
+            if (p.R) v += *(const f32x4_t*)(p.R + (int64_t)m * p.ldr + n);
+            *(f32x4_t*)(p.C + (int64_t)m * p.ldc + n) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm (eps 1e-12, configuration_vit.py:58): one wave per row, D <= 1024
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_fwd_f32_kernel(const float* __restrict__ x, float* __restrict__ h,
+                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (int64_t)row * D;
+    const int nv = D >> 2;
+    f32x4_t v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        v[i] = c < nv ? *(const f32x4_t*)(xr + c * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float d = v[i][k] - mean; q += d * d; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const f32x4_t g = *(const f32x4_t*)(gamma + c * 4), b = *(const f32x4_t*)(beta + c * 4);
+            f32x4_t o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (v[i][k] - mean) * rstd * g[k] + b[k];
+            *(f32x4_t*)(h + (int64_t)row * D + c * 4) = o;
+        }
+    }
+}
+
+// dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dh * gamma
+__global__ __launch_bounds__(256) void ln_bwd_f32_kernel(const float* __restrict__ dh, const float* __restrict__ x,
+                                                         const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                         const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                         float* __restrict__ dx, int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    const int64_t off = (int64_t)row * D;
+    const int nv = D >> 2;
+    f32x4_t g[4], xh[4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        g[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        xh[i] = g[i];
+        if (c < nv) {
+            const f32x4_t d = *(const f32x4_t*)(dh + off + c * 4);
+            const f32x4_t xv = *(const f32x4_t*)(x + off + c * 4);
+            const f32x4_t gm = *(const f32x4_t*)(gamma + c * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                g[i][k] = d[k] * gm[k];
+                xh[i][k] = (xv[k] - mean) * rstd;
+                s1 += g[i][k];
+                s2 += g[i][k] * xh[i][k];
+            }
+        }
+    }
+    const float c1 = wave_sum(s1) / D, c2 = wave_sum(s2) / D;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const f32x4_t r = *(const f32x4_t*)(dres + off + c * 4);
+            f32x4_t o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = r[k] + rstd * (g[i][k] - c1 - xh[i][k] * c2);
+            *(f32x4_t*)(dx + off + c * 4) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// elementwise pieces
+// ---------------------------------------------------------------------------------------------
+__global__ void gelu_fwd_f32_kernel(const float* __restrict__ z, float* __restrict__ a, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) a[i] = gelu_f(z[i]);
+}
+__global__ void gelu_bwd_f32_kernel(float* __restrict__ dz, const float* __restrict__ z, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float x = z[i];
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+        const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+        dz[i] *= cdf + x * pdf;
+    }
+}
+// dst = src * mask (add == 0) or dst += src * mask (add != 0); mask = LoRA dropout keep-mask of (seed, stream)
+__global__ void mask_f32_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n, int add, uint64_t seed,
+                                uint32_t stream, float p, float inv_keep) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float v = src[i] * drop_scale(seed, stream, (uint64_t)i, p, inv_keep);
+        dst[i] = add ? dst[i] + v : v;
+    }
+}
+// pixels [B,3,S,S] -> patches [B*NP, 3*P*P] fp32, (x - mean) / std fused
+__global__ void patch_gather_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int S, int P, int G,
+                                        int normalise, float m0, float m1, float m2, float is0, float is1, float is2) {
+    const int K = 3 * P * P;
+    const int64_t total = (int64_t)B * G * G * K;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int col = (int)(t % K);
+        const int64_t m = t / K;
+        const int c = col / (P * P), rem = col - c * P * P;
+        const int ph = rem / P, pw = rem - ph * P;
+        const int b = (int)(m / (G * G)), pi = (int)(m - (int64_t)b * G * G);
+        const int py = pi / G, px = pi - py * G;
+        float v = x[(((int64_t)b * 3 + c) * S + py * P + ph) * S + px * P + pw];
+        if (normalise) v = (v - (c == 0 ? m0 : (c == 1 ? m1 : m2))) * (c == 0 ? is0 : (c == 1 ? is1 : is2));
+        out[t] = v;
+    }
+}
+// d(pixels)[b,c,y,x] = d(patches)[b*NP + pi][c*P*P + ph*P + pw] * inv_std[c]
+__global__ void patch_scatter_f32_kernel(const float* __restrict__ dp, float* __restrict__ gx, int B, int S, int P, int G,
+                                         float is0, float is1, float is2) {
+    const int K = 3 * P * P;
+    const int64_t total = (int64_t)B * 3 * S * S;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int xx = (int)(t % S);
+        int64_t r = t / S;
+        const int yy = (int)(r % S); r /= S;
+        const int c = (int)(r % 3);
+        const int b = (int)(r / 3);
+        const int py = yy / P, ph = yy - py * P, px = xx / P, pw = xx - px * P;
+        const int64_t m = (int64_t)b * G * G + py * G + px;
+        gx[t] = dp[m * K + c * P * P + ph * P + pw] * (c == 0 ? is0 : (c == 1 ? is1 : is2));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention (HF eager attention, modeling_vit.py:164-189): softmax(Q K^T / 8) V per (image, head),
+// head_dim 64 = one lane per feature.  K and V (backward phase B: Q and dO) of the head live in LDS
+// as rows of 65 floats (conflict-free for both "lane = row" and "lane = feature" reads).
+// ---------------------------------------------------------------------------------------------
+constexpr int AHD = 64, ALD = 65, ATMAX = 224;
+
+struct AttnLds {
+    float* X;      // [T][ALD]
+    float* Y;      // [T][ALD]
+    float* vecA;   // [4][64]  per-wave broadcast row (q / k)
+    float* vecB;   // [4][64]  per-wave broadcast row (dO / v)
+    float* pa;     // [4][ATMAX]
+    float* pb;     // [4][ATMAX]
+    float* delta;  // [ATMAX]
+};
+__device__ __forceinline__ AttnLds attn_lds(float* sm, int T) {
+    AttnLds l;
+    l.X = sm; l.Y = l.X + T * ALD; l.vecA = l.Y + T * ALD; l.vecB = l.vecA + 4 * 64;
+    l.pa = l.vecB + 4 * 64; l.pb = l.pa + 4 * ATMAX; l.delta = l.pb + 4 * ATMAX;
+    return l;
+}
+size_t attn_lds_bytes(int T) { return ((size_t)2 * T * ALD + 8 * 64 + 8 * ATMAX + ATMAX) * sizeof(float); }
+
+__device__ __forceinline__ void attn_stage(float* dst, const float* src, int ld, int T, int tid) {
+    for (int i = tid; i < T * 16; i += 256) {
+        const int r = i >> 4, c4 = (i & 15) * 4;
+        const f32x4_t v = *(const f32x4_t*)(src + (int64_t)r * ld + c4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[r * ALD + c4 + k] = v[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
+                                                           float* __restrict__ lse, int T, int H, int D) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const AttnLds L = attn_lds(sm, T);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.x / H, hd = blockIdx.x - b * H;
+    const int ld = 3 * D;
+    const float* base = qkv + (int64_t)b * T * ld + hd * AHD;
+    attn_stage(L.X, base + D, ld, T, tid);          // K
+    attn_stage(L.Y, base + 2 * D, ld, T, tid);      // V
+    __syncthreads();
+    float* qs = L.vecA + w * 64;
+    float* ps = L.pa + w * ATMAX;
+    for (int q = w; q < T; q += 4) {
+        qs[lane] = base[(int64_t)q * ld + lane];
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        float s[4], mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int key = lane + 64 * j;
+            s[j] = -INFINITY;
+            if (key < T) {
+                float a = 0.f;
+#pragma unroll 16
+                for (int d = 0; d < AHD; ++d) a = fmaf(qs[d], L.X[key * ALD + d], a);
+                s[j] = a * 0.125f;
+            }
+            mx = fmaxf(mx, s[j]);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[j] = (lane + 64 * j < T) ? expf(s[j] - mx) : 0.f; sum += s[j]; }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (lane + 64 * j < T) ps[lane + 64 * j] = s[j] * inv;
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        float o = 0.f;
+        for (int key = 0; key < T; ++key) o = fmaf(ps[key], L.Y[key * ALD + lane], o);
+        ctx[((int64_t)b * T + q) * D + hd * AHD + lane] = o;
+        if (lane == 0) lse[((int64_t)b * H + hd) * T + q] = mx + logf(sum);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+                                                           const float* __restrict__ dctx, const float* __restrict__ lse,
+                                                           float* __restrict__ dqkv, int T, int H, int D) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const AttnLds L = attn_lds(sm, T);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.x / H, hd = blockIdx.x - b * H;
+    const int ld = 3 * D;
+    const float* base = qkv + (int64_t)b * T * ld + hd * AHD;
+    const float* dob = dctx + (int64_t)b * T * D + hd * AHD;
+    const float* ob = ctx + (int64_t)b * T * D + hd * AHD;
+    const float* lrow = lse + ((int64_t)b * H + hd) * T;
+    float* dbase = dqkv + (int64_t)b * T * ld + hd * AHD;
+    float* va = L.vecA + w * 64;
+    float* vb = L.vecB + w * 64;
+    float* pa = L.pa + w * ATMAX;
+    float* pb = L.pb + w * ATMAX;
+    // ---- phase A: dQ (K, V in LDS; one query per wave step) ----
+    attn_stage(L.X, base + D, ld, T, tid);
+    attn_stage(L.Y, base + 2 * D, ld, T, tid);
+    __syncthreads();
+    for (int q = w; q < T; q += 4) {
+        const float qd = base[(int64_t)q * ld + lane], dod = dob[(int64_t)q * D + lane];
+        va[lane] = qd; vb[lane] = dod;
+        const float delta = wave_sum(dod * ob[(int64_t)q * D + lane]);
+        if (lane == 0) L.delta[q] = delta;
+        const float lq = lrow[q];
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int key = lane + 64 * j;
+            if (key < T) {
+                float a = 0.f, dp = 0.f;
+#pragma unroll 16
+                for (int d = 0; d < AHD; ++d) {
+                    a = fmaf(va[d], L.X[key * ALD + d], a);
+                    dp = fmaf(vb[d], L.Y[key * ALD + d], dp);
+                }
+                const float p = expf(a * 0.125f - lq);
+                pa[key] = p * (dp - delta) * 0.125f;        // dS * scale
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        float dq = 0.f;
+        for (int key = 0; key < T; ++key) dq = fmaf(pa[key], L.X[key * ALD + lane], dq);
+        dbase[(int64_t)q * ld + lane] = dq;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // ---- phase B: dK, dV (Q, dO in LDS; one key per wave step) ----
+    attn_stage(L.X, base, ld, T, tid);
+    attn_stage(L.Y, dob, D, T, tid);
+    __syncthreads();
+    for (int key = w; key < T; key += 4) {
+        va[lane] = base[(int64_t)key * ld + D + lane];          // k_j
+        vb[lane] = base[(int64_t)key * ld + 2 * D + lane];      // v_j
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = lane + 64 * j;
+            if (q < T) {
+                float a = 0.f, dp = 0.f;
+#pragma unroll 16
+                for (int d = 0; d < AHD; ++d) {
+                    a = fmaf(L.X[q * ALD + d], va[d], a);
+                    dp = fmaf(L.Y[q * ALD + d], vb[d], dp);
+                }
+                const float p = expf(a * 0.125f - lrow[q]);
+                pa[q] = p;
+                pb[q] = p * (dp - L.delta[q]) * 0.125f;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        float dv = 0.f, dk = 0.f;
+        for (int q = 0; q < T; ++q) {
+            dv = fmaf(pa[q], L.Y[q * ALD + lane], dv);
+            dk = fmaf(pb[q], L.X[q * ALD + lane], dk);
+        }
+        dbase[(int64_t)key * ld + D + lane] = dk;
+        dbase[(int64_t)key * ld + 2 * D + lane] = dv;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+inline int nblk(int64_t n, int t, int cap) {
+    int64_t b = (n + t - 1) / t;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+int f32_init(int device) {
+    static bool done[64] = {};
+    if (device < 0 || device >= 64) return -1;
+    if (done[device]) return 0;
+    const int bytes = (int)attn_lds_bytes(ATMAX);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)attn_bwd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    done[device] = true;
+    return 0;
+}
+
+void k_gemm_f32(const GemmF32& g, hipStream_t s) {
+    ProfScope prof_("gemm_f32_kernel", 2.0 * g.M * (double)g.N * g.K, 0.0, s);
+    dim3 grid((g.N + FBN - 1) / FBN, (g.M + FBM - 1) / FBM);
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, g);
+}
+void k_ln_fwd_f32(const float* x, float* h, float* mean, float* rstd, const float* g, const float* b, int M, int D,
+                  float eps, hipStream_t s) {
+    hipLaunchKernelGGL(ln_fwd_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, h, mean, rstd, g, b, M, D, eps);
+}
+void k_ln_bwd_f32(const float* dh, const float* x, const float* mean, const float* rstd, const float* g, const float* dres,
+                  float* dx, int M, int D, hipStream_t s) {
+    hipLaunchKernelGGL(ln_bwd_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, M, D);
+}
+void k_gelu_fwd_f32(const float* z, float* a, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(gelu_fwd_f32_kernel, dim3(nblk(n, 256, 8192)), dim3(256), 0, s, z, a, n);
+}
+void k_gelu_bwd_f32(float* dz, const float* z, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(gelu_bwd_f32_kernel, dim3(nblk(n, 256, 8192)), dim3(256), 0, s, dz, z, n);
+}
+void k_mask_f32(float* dst, const float* src, int64_t n, int add, uint64_t seed, uint32_t stream, float p, hipStream_t s) {
+    hipLaunchKernelGGL(mask_f32_kernel, dim3(nblk(n, 256, 8192)), dim3(256), 0, s, dst, src, n, add, seed, stream, p,
+                       1.f / (1.f - p));
+}
+void k_patch_gather_f32(const float* x, float* out, int B, int S, int P, int normalise, const float* mean, const float* std,
+                        hipStream_t s) {
+    const int G = S / P;
+    hipLaunchKernelGGL(patch_gather_f32_kernel, dim3(nblk((int64_t)B * G * G * 3 * P * P, 256, 8192)), dim3(256), 0, s, x,
+                       out, B, S, P, G, normalise, mean[0], mean[1], mean[2], 1.f / std[0], 1.f / std[1], 1.f / std[2]);
+}
+void k_patch_scatter_f32(const float* dp, float* gx, int B, int S, int P, const float inv_std[3], hipStream_t s) {
+    const int G = S / P;
+    hipLaunchKernelGGL(patch_scatter_f32_kernel, dim3(nblk((int64_t)B * 3 * S * S, 256, 8192)), dim3(256), 0, s, dp, gx, B,
+                       S, P, G, inv_std[0], inv_std[1], inv_std[2]);
+}
+int k_attn_fwd_f32(const float* qkv, float* ctx, float* lse, int B, int T, int H, int D, hipStream_t s) {
+    if (T > ATMAX) return -1;
+    ProfScope prof_("attn_fwd_f32_kernel", 4.0 * B * H * (double)T * T * AHD, 0.0, s);
+    hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(B * H), dim3(256), attn_lds_bytes(T), s, qkv, ctx, lse, T, H, D);
+    return 0;
+}
+int k_attn_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const float* lse, float* dqkv, int B, int T, int H,
+                   int D, hipStream_t s) {
+    if (T > ATMAX) return -1;
+    ProfScope prof_("attn_bwd_f32_kernel", 10.0 * B * H * (double)T * T * AHD, 0.0, s);
+    hipLaunchKernelGGL(attn_bwd_f32_kernel, dim3(B * H), dim3(256), attn_lds_bytes(T), s, qkv, ctx, dctx, lse, dqkv, T, H, D);
+    return 0;
+}

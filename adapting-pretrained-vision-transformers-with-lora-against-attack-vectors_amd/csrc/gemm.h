@@ -3,23 +3,23 @@
 #include "common.h"
 
 // C[M,N] = A1[M,K1] * W1[N,K1]^T + A2[M,K2] * W2[N,K2]^T  (+ epilogue)
-// Both operands are K-contiguous bf16 ("NT" form); the optional second pair is the
+// Both operands are K-contiguous h16 ("NT" form); the optional second pair is the
 // rank-r LoRA update appended as extra K tiles:  [x | x A^T] * [W | s B]^T.
 enum GemmEpilogue {
-    EPI_STORE_BF16 = 0,   // C(bf16) = acc + bias
+    EPI_STORE_H16 = 0,   // C(h16) = acc + bias
     EPI_RESID_F32 = 1,    // C(f32)  = acc + bias + R(f32)        (R may alias C)
-    EPI_GELU = 2,         // z = acc + bias ; C(bf16) = gelu(z) ; C2(bf16) = gelu'(z)
-    EPI_GELU_BWD = 3,     // C(bf16) = acc * R(bf16), R = the saved gelu'(z)
+    EPI_GELU = 2,         // z = acc + bias ; C(h16) = gelu(z) ; C2(h16) = gelu'(z)
+    EPI_GELU_BWD = 3,     // C(h16) = acc * R(h16), R = the saved gelu'(z)
     EPI_PATCH_FWD = 4,    // C(f32)[row b*T + 1 + p] = acc + bias + pos[1+p]
     EPI_PATCH_BWD = 5,    // image-layout scatter of d(patches), scaled by 1/std[c]
     EPI_STORE_F32 = 6,    // C(f32) = acc + bias
     EPI_NONE = 7,         // diagnostic: results kept live, nothing stored (timing of the main loop alone)
-    EPI_DROP_ACC = 8,     // train-mode LoRA dgrad with dropout: C(bf16) = (R(bf16) + mask*acc) [* G(bf16)]
+    EPI_DROP_ACC = 8,     // train-mode LoRA dgrad with dropout: C(h16) = (R(h16) + mask*acc) [* G(h16)]
 };
 
 struct GemmArgs {
-    const bf16* A1; const bf16* W1; int lda1, ldw1, K1;
-    const bf16* A2; const bf16* W2; int lda2, ldw2, K2;
+    const h16* A1; const h16* W1; int lda1, ldw1, K1;
+    const h16* A2; const h16* W2; int lda2, ldw2, K2;
     int M;            // rows computed (multiple of 128; buffers are padded to it)
     int Mvalid;       // rows that may be stored by the remapping epilogues
     int N;            // multiple of BN
@@ -30,6 +30,7 @@ struct GemmArgs {
     // patch epilogues
     const float* pos; int tokens; int patches; int grid; int psize; int img;
     float inv_std[3];
+    const float* row_scale;   // EPI_PATCH_BWD: optional per-IMAGE factor (undoes the fp16 gradient scale), nullptr = 1
     // A-row gather for the patch-embedding backward: GEMM row m = b*patches + p reads A row
     // b*tokens + 1 + p (the non-CLS rows of the token-major gradient); 0 = off
     int a_gather;
@@ -39,10 +40,10 @@ struct GemmArgs {
 
     int dephase;      // gemm256: start offset unit (x 8128 cycles x (workgroup/8 mod 4)); 0 = off
     // EPI_DROP_ACC: dropout mask of element (m, n) of the module input = drop_scale(seed, stream, m*N + n)
-    const bf16* G; int ldg;          // optional extra factor (gelu'(z) for the fc2 input gradient)
+    const h16* G; int ldg;          // optional extra factor (gelu'(z) for the fc2 input gradient)
     uint64_t drop_seed; uint32_t drop_stream; float drop_p, drop_inv_keep;
 };
 
 // bn = 128 (default) or 64 (skinny LoRA-down GEMMs)
 void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s);
-void gemm_init();   // one-time kernel attributes (outside any stream capture)
+int gemm_init(int device);   // per-device kernel attributes (outside any stream capture); 0 = ok

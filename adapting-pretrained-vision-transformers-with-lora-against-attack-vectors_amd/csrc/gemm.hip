@@ -1,4 +1,4 @@
-// bf16 MFMA GEMM for gfx950 with fused epilogues and the LoRA rank-r update appended as
+// h16 MFMA GEMM for gfx950 with fused epilogues and the LoRA rank-r update appended as
 // extra K tiles.  Stands in for the cuBLAS/MKL matmuls that HF ViT + peft issue on the
 // reference's hot path (whitebox_attacks.py:27, train_loras.py:310; SURVEY.md K2,K4,K6-K8).
 //
@@ -16,7 +16,7 @@
 
 void launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);   // gemm256.hip
 bool gemm256_supports(const GemmArgs& a, int epi);
-void gemm256_init();
+int gemm256_init();
 
 namespace {
 
@@ -28,8 +28,8 @@ constexpr int BK = 64;
 template <int BM, int BN, int EPI, int STAGES = 2>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* sA = (bf16*)smem;                   // [STAGES][BM][BK]
-    bf16* sW = sA + STAGES * BM * BK;         // [STAGES][BN][BK]
+    h16* sA = (h16*)smem;                   // [STAGES][BM][BK]
+    h16* sW = sA + STAGES * BM * BK;         // [STAGES][BN][BK]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tilesN = p.N / BN;
@@ -63,11 +63,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
     }
 
     auto issue = [&](int kt, int buf) {
-        const bf16* Ap; const bf16* Wp; int lda, ldw, k0;
+        const h16* Ap; const h16* Wp; int lda, ldw, k0;
         if (kt < nk1) { Ap = p.A1; Wp = p.W1; lda = p.lda1; ldw = p.ldw1; k0 = kt * BK; }
         else          { Ap = p.A2; Wp = p.W2; lda = p.lda2; ldw = p.ldw2; k0 = (kt - nk1) * BK; }
-        bf16* dA = sA + buf * BM * BK;
-        bf16* dW = sW + buf * BN * BK;
+        h16* dA = sA + buf * BM * BK;
+        h16* dW = sW + buf * BN * BK;
 #pragma unroll
         for (int i = 0; i < AG; ++i) {
             const int g = w * AG + i;
@@ -103,22 +103,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
         asm volatile("s_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
-        const bf16* cA = sA + (kt % STAGES) * BM * BK;
-        const bf16* cW = sW + (kt % STAGES) * BN * BK;
+        const h16* cA = sA + (kt % STAGES) * BM * BK;
+        const h16* cW = sW + (kt % STAGES) * BN * BK;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[MI], wf[NJ];
+            h16x8 af[MI], wf[NJ];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int r = wm * (BM / 2) + i * 16 + fr;
                 const int c = (ks * 4 + fg) ^ (r & 7);
-                af[i] = *(const bf16x8*)(cA + r * BK + c * 8);
+                af[i] = *(const h16x8*)(cA + r * BK + c * 8);
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int r = wn * (BN / 2) + j * 16 + fr;
                 const int c = (ks * 4 + fg) ^ (r & 7);
-                wf[j] = *(const bf16x8*)(cW + r * BK + c * 8);
+                wf[j] = *(const h16x8*)(cW + r * BK + c * 8);
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -151,14 +151,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
 template <int BN, int EPI, int BM = 128, int STAGES = 2>
 void launch_t(const GemmArgs& a, hipStream_t s) {
     const int ntiles = (a.M / BM) * (a.N / BN);
-    const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(bf16);
+    const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(h16);
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, EPI, STAGES>), dim3(ntiles), dim3(256), lds, s, a);
 }
 
+int g_attr_err = 0;
 template <int BN, int EPI, int BM = 128, int STAGES = 2>
 void set_attr() {
-    const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(bf16);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, EPI, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(h16);
+    const hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, EPI, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) g_attr_err = (int)e;
 }
 
 int g_force_small = -1;
@@ -166,13 +168,15 @@ int g_dephase = -1;
 
 }  // namespace
 
-void gemm_init() {
-    static bool done = false;
-    if (done) return;
-    set_attr<64, EPI_STORE_BF16>();
-    set_attr<64, EPI_STORE_BF16, 64, 4>();
-    set_attr<64, EPI_STORE_BF16, 128, 2>();
-    set_attr<128, EPI_STORE_BF16>();
+int gemm_init(int device) {
+    static bool done[64] = {};
+    if (device < 0 || device >= 64) return -1;
+    if (done[device]) return 0;
+    g_attr_err = 0;
+    set_attr<64, EPI_STORE_H16>();
+    set_attr<64, EPI_STORE_H16, 64, 4>();
+    set_attr<64, EPI_STORE_H16, 128, 2>();
+    set_attr<128, EPI_STORE_H16>();
     set_attr<128, EPI_RESID_F32>();
     set_attr<128, EPI_GELU>();
     set_attr<128, EPI_GELU_BWD>();
@@ -180,12 +184,14 @@ void gemm_init() {
     set_attr<128, EPI_PATCH_BWD>();
     set_attr<128, EPI_STORE_F32>();
     set_attr<128, EPI_DROP_ACC>();
-    gemm256_init();
+    if (int e2 = gemm256_init()) g_attr_err = e2;
     const char* e = getenv("VITLORA_GEMM128");      // A/B switch: force the 128-row kernel
     g_force_small = (e && e[0] == '1') ? 1 : 0;
     const char* dp = getenv("VITLORA_DEPHASE");      // experiment knob: start-offset unit of gemm256
     if (dp) g_dephase = atoi(dp);
-    done = true;
+    if (g_attr_err) return g_attr_err;
+    done[device] = true;
+    return 0;
 }
 
 void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
@@ -203,12 +209,12 @@ void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
     if (bn == 64) {
         switch (epi) {
             // skinny LoRA-down product (HBM-bound on A): 64-row tiles -> 3x more workgroups in flight
-            case EPI_STORE_BF16: launch_t<64, EPI_STORE_BF16, 128, 2>(a, s); return;
+            case EPI_STORE_H16: launch_t<64, EPI_STORE_H16, 128, 2>(a, s); return;
             default: break;
         }
     }
     switch (epi) {
-        case EPI_STORE_BF16: launch_t<128, EPI_STORE_BF16>(a, s); break;
+        case EPI_STORE_H16: launch_t<128, EPI_STORE_H16>(a, s); break;
         case EPI_RESID_F32: launch_t<128, EPI_RESID_F32>(a, s); break;
         case EPI_GELU: launch_t<128, EPI_GELU>(a, s); break;
         case EPI_GELU_BWD: launch_t<128, EPI_GELU_BWD>(a, s); break;

@@ -1,6 +1,6 @@
 // Main GEMM of the path: 256 x 256 x 64 tiles, 8 waves (2 x 4), one PERSISTENT workgroup per
-// CU, 16x16x32 bf16 MFMA, fused epilogues (gemm_epi.h) and the LoRA update as extra K tiles.
-// C[M,N] = A1 W1^T + A2 W2^T, all operands K-contiguous bf16.
+// CU, 16x16x32 h16 MFMA, fused epilogues (gemm_epi.h) and the LoRA update as extra K tiles.
+// C[M,N] = A1 W1^T + A2 W2^T, all operands K-contiguous h16.
 //
 // Pipeline (four phases per 64-deep K tile, 4 half-tiles of loads in flight):
 //   * LDS holds two K tiles (2 x (BM + 256) rows of 128 B, XOR-swizzled 16-byte chunks).
@@ -55,7 +55,7 @@ constexpr int BK = 64;
 // tile's first loads and its main loop in the in-order vmcnt queue.
 template <int EPI>
 constexpr int epilogue_vmem_per_row() {
-    return EPI == EPI_STORE_BF16 ? 2 : EPI == EPI_STORE_F32 ? 4 : EPI == EPI_RESID_F32 ? 8
+    return EPI == EPI_STORE_H16 ? 2 : EPI == EPI_STORE_F32 ? 4 : EPI == EPI_RESID_F32 ? 8
          : EPI == EPI_GELU ? 4 : EPI == EPI_GELU_BWD ? 4 : 0;
 }
 constexpr int clamp63(int v) { return v > 63 ? 63 : v; }
@@ -84,7 +84,7 @@ __device__ __forceinline__ void glds4_sv(const void* sbase, unsigned voff, const
 template <int BM, int EPI>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntiles, int bm0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* sm = (bf16*)smem;
+    h16* sm = (h16*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 2, wn = w & 3;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
         const bool ext = T >= nk1;
         const char* Ap = (const char*)(ext ? p.A2 : p.A1);
         const unsigned lda = ext ? p.lda2 : p.lda1, k0 = (ext ? T - nk1 : T) * BK, vo = ext ? voA2 : voA1;
-        bf16* dst = sm + (T & 1) * BUF;
+        h16* dst = sm + (T & 1) * BUF;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int g = w * NA + i;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
         const bool ext = T >= nk1;
         const char* Wp = (const char*)(ext ? p.W2 : p.W1);
         const unsigned ldw = ext ? p.ldw2 : p.ldw1, k0 = (ext ? T - nk1 : T) * BK, vo = ext ? voW2 : voW1;
-        bf16* dst = sm + (T & 1) * BUF + BM * BK;
+        h16* dst = sm + (T & 1) * BUF + BM * BK;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int g = w * 2 + i;
@@ -160,26 +160,26 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
         const int w_base = BM * BK + (wn * 64 + fr) * BK;        // + nh*32*BK + j*16*BK
 
         f32x4 acc[2 * MI][4];
-        bf16x8 af[2][MI], wf[2][2][2];
+        h16x8 af[2][MI], wf[2][2][2];
 #pragma unroll
         for (int i = 0; i < 2 * MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        auto readA = [&](const bf16* buf, int mh) {
+        auto readA = [&](const h16* buf, int mh) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                const bf16* r = buf + a_base + (mh * (BM / 4) + i * 16) * BK;
-                af[0][i] = *(const bf16x8*)(r + xo0);
-                af[1][i] = *(const bf16x8*)(r + xo1);
+                const h16* r = buf + a_base + (mh * (BM / 4) + i * 16) * BK;
+                af[0][i] = *(const h16x8*)(r + xo0);
+                af[1][i] = *(const h16x8*)(r + xo1);
             }
         };
-        auto readW = [&](const bf16* buf, int nh) {
+        auto readW = [&](const h16* buf, int nh) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const bf16* r = buf + w_base + (nh * 32 + j * 16) * BK;
-                wf[nh][0][j] = *(const bf16x8*)(r + xo0);
-                wf[nh][1][j] = *(const bf16x8*)(r + xo1);
+                const h16* r = buf + w_base + (nh * 32 + j * 16) * BK;
+                wf[nh][0][j] = *(const h16x8*)(r + xo0);
+                wf[nh][1][j] = *(const h16x8*)(r + xo1);
             }
         };
         // lower_only: the K tile's upper 32 columns are zero on both sides (LoRA tile with r * modules <= 32)
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
         auto ktile = [&](int T, auto mode, auto extra) {
             constexpr int MODE = decltype(mode)::value;
             constexpr int EXC = decltype(extra)::value;
-            const bf16* buf = sm + (T & 1) * BUF;
+            const h16* buf = sm + (T & 1) * BUF;
             // P1
             readA(buf, 0);
             readW(buf, 0);
@@ -264,12 +264,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
             // the saved gelu'(z) of a whole half of the wave's rows is requested before any of it is used or any
             // result is stored (the stores may alias as far as the compiler knows, so it would not hoist the loads
             // itself): two memory round trips per output tile instead of eight
-            bf16x8 rz[2 * MI][2];
+            h16x8 rz[2 * MI][2];
 #pragma unroll
             for (int i = 0; i < 2 * MI; ++i) {
-                const bf16* zs = (const bf16*)p.R + (size_t)(bm * BM + wm * (BM / 2) + i * 16 + fr) * p.ldr + n0;
-                rz[i][0] = *(const bf16x8*)zs;
-                rz[i][1] = *(const bf16x8*)(zs + 8);
+                const h16* zs = (const h16*)p.R + (size_t)(bm * BM + wm * (BM / 2) + i * 16 + fr) * p.ldr + n0;
+                rz[i][0] = *(const h16x8*)zs;
+                rz[i][1] = *(const h16x8*)(zs + 8);
             }
 #pragma unroll
             for (int i = 0; i < 2 * MI; ++i) {
@@ -349,7 +349,7 @@ void launch_one(const GemmArgs& a, int ntiles, int bm0, hipStream_t s) {
     const double valid = a.Mvalid ? (double)a.Mvalid / a.M : 1.0;
     ProfScope prof_(name, 2.0 * rows * valid * (a.n_algo ? a.n_algo : a.N) * (a.K1 + (a.k2_algo ? a.k2_algo : a.K2)), 0.0, s);
     const int grid = ntiles < g_num_cus ? ntiles : g_num_cus;
-    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16) + 1024;
+    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(h16) + 1024;
     hipLaunchKernelGGL((gemm256_kernel<BM, EPI>), dim3(grid), dim3(512), lds, s, a, ntiles, bm0);
 }
 
@@ -361,10 +361,12 @@ void launch_t(const GemmArgs& a, hipStream_t s) {
     launch_one<128, EPI>(a, nsmall, (nbig / (a.N / BN)) * 2, s);
 }
 
+int g_attr_err256 = 0;
 template <int BM, int EPI>
 void set_attr1() {
-    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16) + 1024;
-    (void)hipFuncSetAttribute((const void*)gemm256_kernel<BM, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(h16) + 1024;
+    const hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<BM, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) g_attr_err256 = (int)e;
 }
 template <int EPI>
 void set_attr() { set_attr1<256, EPI>(); set_attr1<128, EPI>(); }
@@ -380,19 +382,21 @@ bool gemm256_supports(const GemmArgs& a, int epi) {
     return plan_tiles(a.M, a.N, g_num_cus ? g_num_cus : 256, &nb, &ns);
 }
 
-void gemm256_init() {
+int gemm256_init() {
+    g_attr_err256 = 0;
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
         g_num_cus = prop.multiProcessorCount;
     if (g_num_cus <= 0) g_num_cus = 256;
-    set_attr<EPI_STORE_BF16>(); set_attr<EPI_RESID_F32>(); set_attr<EPI_GELU>(); set_attr<EPI_GELU_BWD>();
+    set_attr<EPI_STORE_H16>(); set_attr<EPI_RESID_F32>(); set_attr<EPI_GELU>(); set_attr<EPI_GELU_BWD>();
     set_attr<EPI_PATCH_FWD>(); set_attr<EPI_PATCH_BWD>(); set_attr<EPI_STORE_F32>(); set_attr<EPI_NONE>();
+    return g_attr_err256;
 }
 
 void launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
     switch (epi) {
-        case EPI_STORE_BF16: launch_t<EPI_STORE_BF16>(a, s); break;
+        case EPI_STORE_H16: launch_t<EPI_STORE_H16>(a, s); break;
         case EPI_RESID_F32: launch_t<EPI_RESID_F32>(a, s); break;
         case EPI_GELU: launch_t<EPI_GELU>(a, s); break;
         case EPI_GELU_BWD: launch_t<EPI_GELU_BWD>(a, s); break;

@@ -26,43 +26,43 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
 
 template <int EPI>
 __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, f32x4 v) {
-    if constexpr (EPI == EPI_STORE_BF16) {
-        bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        *(bf16x4*)((bf16*)p.C + (size_t)m * p.ldc + n) = o;
+    if constexpr (EPI == EPI_STORE_H16) {
+        h16x4 o = {f2h(v[0]), f2h(v[1]), f2h(v[2]), f2h(v[3])};
+        *(h16x4*)((h16*)p.C + (size_t)m * p.ldc + n) = o;
     } else if constexpr (EPI == EPI_STORE_F32) {
         *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
     } else if constexpr (EPI == EPI_RESID_F32) {
         const f32x4 r = *(const f32x4*)((const float*)p.R + (size_t)m * p.ldr + n);
         *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v + r;
     } else if constexpr (EPI == EPI_GELU) {
-        bf16x4 g, a;
+        h16x4 g, a;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const GeluParts gp = gelu_parts(v[i]);
-            a[i] = f2bf(v[i] * gp.cdf);
-            g[i] = f2bf(fmaf(v[i], gp.pdf, gp.cdf));
+            a[i] = f2h(v[i] * gp.cdf);
+            g[i] = f2h(fmaf(v[i], gp.pdf, gp.cdf));
         }
-        *(bf16x4*)((bf16*)p.C2 + (size_t)m * p.ldc2 + n) = g;
-        *(bf16x4*)((bf16*)p.C + (size_t)m * p.ldc + n) = a;
+        *(h16x4*)((h16*)p.C2 + (size_t)m * p.ldc2 + n) = g;
+        *(h16x4*)((h16*)p.C + (size_t)m * p.ldc + n) = a;
     } else if constexpr (EPI == EPI_GELU_BWD) {
-        const bf16x4 z = *(const bf16x4*)((const bf16*)p.R + (size_t)m * p.ldr + n);
-        bf16x4 o;
+        const h16x4 z = *(const h16x4*)((const h16*)p.R + (size_t)m * p.ldr + n);
+        h16x4 o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = f2bf(v[i] * bf2f(z[i]));
-        *(bf16x4*)((bf16*)p.C + (size_t)m * p.ldc + n) = o;
+        for (int i = 0; i < 4; ++i) o[i] = f2h(v[i] * h2f(z[i]));
+        *(h16x4*)((h16*)p.C + (size_t)m * p.ldc + n) = o;
     } else if constexpr (EPI == EPI_DROP_ACC) {
         // d(input) = R + mask * (u (sA)) [* gelu'(z)]: the LoRA branch saw the dropped input
-        const bf16x4 r = *(const bf16x4*)((const bf16*)p.R + (size_t)m * p.ldr + n);
-        bf16x4 o;
+        const h16x4 r = *(const h16x4*)((const h16*)p.R + (size_t)m * p.ldr + n);
+        h16x4 o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float ms = drop_scale(p.drop_seed, p.drop_stream, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + i),
                                         p.drop_p, p.drop_inv_keep);
-            float t = bf2f(r[i]) + ms * v[i];
-            if (p.G) t *= bf2f(p.G[(size_t)m * p.ldg + n + i]);
-            o[i] = f2bf(t);
+            float t = h2f(r[i]) + ms * v[i];
+            if (p.G) t *= h2f(p.G[(size_t)m * p.ldg + n + i]);
+            o[i] = f2h(t);
         }
-        *(bf16x4*)((bf16*)p.C + (size_t)m * p.ldc + n) = o;
+        *(h16x4*)((h16*)p.C + (size_t)m * p.ldc + n) = o;
     } else if constexpr (EPI == EPI_PATCH_FWD) {
         if (m < p.Mvalid) {
             const int b = m / p.patches, pi = m - b * p.patches;
@@ -76,7 +76,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
             const int pp = p.psize * p.psize;
             const int c = n / pp, rem = n - c * pp;
             const int ph = rem / p.psize, pw = rem - ph * p.psize;
-            const float s = p.inv_std[c];
+            const float s = p.inv_std[c] * (p.row_scale ? p.row_scale[b] : 1.f);
             f32x4 o = {v[0] * s, v[1] * s, v[2] * s, v[3] * s};
             float* dst = (float*)p.C + (((size_t)b * 3 + c) * p.img + py * p.psize + ph) * p.img +
                          px * p.psize + pw;
@@ -86,35 +86,35 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
 }
 
 // GELU_BWD on 16 columns with gelu'(z) already in registers (z0 = columns 0..7, z1 = 8..15)
-__device__ __forceinline__ void epilogue_gelu_bwd16(const GemmArgs& p, int m, int n0, const f32x4 (&v)[4], bf16x8 z0, bf16x8 z1) {
-    bf16x8 lo, hi;
+__device__ __forceinline__ void epilogue_gelu_bwd16(const GemmArgs& p, int m, int n0, const f32x4 (&v)[4], h16x8 z0, h16x8 z1) {
+    h16x8 lo, hi;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        lo[k] = f2bf(v[0][k] * bf2f(z0[k]));
-        lo[4 + k] = f2bf(v[1][k] * bf2f(z0[4 + k]));
-        hi[k] = f2bf(v[2][k] * bf2f(z1[k]));
-        hi[4 + k] = f2bf(v[3][k] * bf2f(z1[4 + k]));
+        lo[k] = f2h(v[0][k] * h2f(z0[k]));
+        lo[4 + k] = f2h(v[1][k] * h2f(z0[4 + k]));
+        hi[k] = f2h(v[2][k] * h2f(z1[k]));
+        hi[4 + k] = f2h(v[3][k] * h2f(z1[4 + k]));
     }
-    bf16* dst = (bf16*)p.C + (size_t)m * p.ldc + n0;
-    *(bf16x8*)dst = lo;
-    *(bf16x8*)(dst + 8) = hi;
+    h16* dst = (h16*)p.C + (size_t)m * p.ldc + n0;
+    *(h16x8*)dst = lo;
+    *(h16x8*)(dst + 8) = hi;
 }
 
 // 16 consecutive output columns n0..n0+15 of row m held by one lane as v[0..3] (the 256-row
 // kernel permutes the W rows of its LDS image so that a lane's four column tiles are adjacent):
-// 16-byte loads / stores, 64 B (bf16) or 256 B (f32) contiguous per row and lane quad.
+// 16-byte loads / stores, 64 B (h16) or 256 B (f32) contiguous per row and lane quad.
 template <int EPI>
 __device__ __forceinline__ void epilogue_row16(const GemmArgs& p, int m, int n0, const f32x4 (&v)[4]) {
     auto pack8 = [](const f32x4& a, const f32x4& b) {
-        bf16x8 o;
+        h16x8 o;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { o[k] = f2bf(a[k]); o[4 + k] = f2bf(b[k]); }
+        for (int k = 0; k < 4; ++k) { o[k] = f2h(a[k]); o[4 + k] = f2h(b[k]); }
         return o;
     };
-    if constexpr (EPI == EPI_STORE_BF16) {
-        bf16* dst = (bf16*)p.C + (size_t)m * p.ldc + n0;
-        *(bf16x8*)dst = pack8(v[0], v[1]);
-        *(bf16x8*)(dst + 8) = pack8(v[2], v[3]);
+    if constexpr (EPI == EPI_STORE_H16) {
+        h16* dst = (h16*)p.C + (size_t)m * p.ldc + n0;
+        *(h16x8*)dst = pack8(v[0], v[1]);
+        *(h16x8*)(dst + 8) = pack8(v[2], v[3]);
     } else if constexpr (EPI == EPI_STORE_F32) {
         float* dst = (float*)p.C + (size_t)m * p.ldc + n0;
 #pragma unroll
@@ -140,16 +140,16 @@ __device__ __forceinline__ void epilogue_row16(const GemmArgs& p, int m, int n0,
                 a[q][k] = v[q][k] * gp.cdf;
                 g[q][k] = fmaf(v[q][k], gp.pdf, gp.cdf);
             }
-        bf16* gd = (bf16*)p.C2 + (size_t)m * p.ldc2 + n0;
-        bf16* ad = (bf16*)p.C + (size_t)m * p.ldc + n0;
-        *(bf16x8*)gd = pack8(g[0], g[1]);
-        *(bf16x8*)(gd + 8) = pack8(g[2], g[3]);
-        *(bf16x8*)ad = pack8(a[0], a[1]);
-        *(bf16x8*)(ad + 8) = pack8(a[2], a[3]);
+        h16* gd = (h16*)p.C2 + (size_t)m * p.ldc2 + n0;
+        h16* ad = (h16*)p.C + (size_t)m * p.ldc + n0;
+        *(h16x8*)gd = pack8(g[0], g[1]);
+        *(h16x8*)(gd + 8) = pack8(g[2], g[3]);
+        *(h16x8*)ad = pack8(a[0], a[1]);
+        *(h16x8*)(ad + 8) = pack8(a[2], a[3]);
     } else if constexpr (EPI == EPI_GELU_BWD) {
         // R = gelu'(z) saved by the forward epilogue
-        const bf16* zs = (const bf16*)p.R + (size_t)m * p.ldr + n0;
-        epilogue_gelu_bwd16(p, m, n0, v, *(const bf16x8*)zs, *(const bf16x8*)(zs + 8));
+        const h16* zs = (const h16*)p.R + (size_t)m * p.ldr + n0;
+        epilogue_gelu_bwd16(p, m, n0, v, *(const h16x8*)zs, *(const h16x8*)(zs + 8));
     } else if constexpr (EPI == EPI_NONE) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) asm volatile("" ::"v"(v[q]));

@@ -5,7 +5,7 @@
 // operand (768..3072 columns), R = the rank-r operand (<= 64 columns).
 //
 // Both operands are token-major, i.e. the summed index m is the ROW of both: each 32-token step
-// is staged into LDS as two swizzled [32][64] bf16 images and BOTH MFMA operands are read with the
+// is staged into LDS as two swizzled [32][64] h16 images and BOTH MFMA operands are read with the
 // hardware-transposed ds_read_b64_tr_b16 (same k order on both sides).  A workgroup owns 64 columns
 // of L and a chunk of tokens; partial results are added to the fp32 output with atomics (the
 // output was zeroed by the caller; one add per element per token chunk).  HBM-bound on L.
@@ -19,24 +19,24 @@ constexpr int MCHUNK = 512;     // tokens per workgroup
 
 // transposed fragment of a swizzled [rows][64] image (chunk c of row r at c ^ (r & 7)):
 // element j of lane (fr, fg) = img[r0 + 16*(j>>2) + 4*fg + (j&3)][c0 + fr]
-__device__ __forceinline__ bf16x8 tr_frag16(const bf16* img, int r0, int c0, int fr, int fg) {
+__device__ __forceinline__ h16x8 tr_frag16(const h16* img, int r0, int c0, int fr, int fg) {
     const int p = fr & 3;
     const int row = r0 + 4 * fg + (fr >> 2);
     const int chunk = (c0 >> 3) + (p >> 1);
-    const bf16* a0 = img + row * HD + ((chunk ^ (row & 7)) << 3) + ((p & 1) << 2);
+    const h16* a0 = img + row * HD + ((chunk ^ (row & 7)) << 3) + ((p & 1) << 2);
     const int row1 = row + 16;
-    const bf16* a1 = img + row1 * HD + ((chunk ^ (row1 & 7)) << 3) + ((p & 1) << 2);
+    const h16* a1 = img + row1 * HD + ((chunk ^ (row1 & 7)) << 3) + ((p & 1) << 2);
     return cat4(lds_read_tr16(a0), lds_read_tr16(a1));
 }
 
 // NRT = 16-column tiles of R covered (ncr <= 16*NRT)
 template <int NRT>
-__global__ __launch_bounds__(256) void lora_wgrad_mfma_kernel(const bf16* __restrict__ L, int ldl, int ncl,
-                                                              const bf16* __restrict__ R, int ldr, int ncr, int M,
+__global__ __launch_bounds__(256) void lora_wgrad_mfma_kernel(const h16* __restrict__ L, int ldl, int ncl,
+                                                              const h16* __restrict__ R, int ldr, int ncr, int M,
                                                               float scale, float* __restrict__ out, int ldo,
-                                                              int transpose_out) {
-    __shared__ __attribute__((aligned(16))) bf16 sL[32 * HD];
-    __shared__ __attribute__((aligned(16))) bf16 sR[32 * HD];
+                                                              int transpose_out, const float* __restrict__ inv_gscale) {
+    __shared__ __attribute__((aligned(16))) h16 sL[32 * HD];
+    __shared__ __attribute__((aligned(16))) h16 sR[32 * HD];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int i0 = blockIdx.x * 64;                 // first L column of this workgroup
@@ -51,17 +51,17 @@ __global__ __launch_bounds__(256) void lora_wgrad_mfma_kernel(const bf16* __rest
     f32x4 acc[NRT];
 #pragma unroll
     for (int t = 0; t < NRT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 zero;
+    h16x8 zero;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) zero[k] = (bf16)0.f;
+    for (int k = 0; k < 8; ++k) zero[k] = (h16)0.f;
 
-    auto load = [&](int m0, bf16x8& lv, bf16x8& rv) {
+    auto load = [&](int m0, h16x8& lv, h16x8& rv) {
         const int m = m0 + srow;
         lv = zero; rv = zero;
         if (m < m_end) {
-            if (l_ok) lv = *(const bf16x8*)(L + (size_t)m * ldl + i0 + sc * 8);
+            if (l_ok) lv = *(const h16x8*)(L + (size_t)m * ldl + i0 + sc * 8);
             if (r_ok) {
-                if (r_vec) rv = *(const bf16x8*)(R + (size_t)m * ldr + sc * 8);
+                if (r_vec) rv = *(const h16x8*)(R + (size_t)m * ldr + sc * 8);
                 else {
 #pragma unroll
                     for (int k = 0; k < 8; ++k)
@@ -70,20 +70,21 @@ __global__ __launch_bounds__(256) void lora_wgrad_mfma_kernel(const bf16* __rest
             }
         }
     };
-    bf16x8 lv, rv;
+    h16x8 lv, rv;
     load(m_begin, lv, rv);
     for (int m0 = m_begin; m0 < m_end; m0 += 32) {
         __syncthreads();                            // previous step's fragment reads are done
-        *(bf16x8*)(sL + srow * HD + ((sc ^ (srow & 7)) << 3)) = lv;
-        *(bf16x8*)(sR + srow * HD + ((sc ^ (srow & 7)) << 3)) = rv;
+        *(h16x8*)(sL + srow * HD + ((sc ^ (srow & 7)) << 3)) = lv;
+        *(h16x8*)(sR + srow * HD + ((sc ^ (srow & 7)) << 3)) = rv;
         __syncthreads();
         if (m0 + 32 < m_end) load(m0 + 32, lv, rv); // next step's global loads fly under the MFMAs
         // D[row = j (R column)][col = i (L column)] += sum_m R[m][j] * L[m][i]
-        const bf16x8 lb = tr_frag16(sL, 0, w * 16, fr, fg);
+        const h16x8 lb = tr_frag16(sL, 0, w * 16, fr, fg);
 #pragma unroll
         for (int t = 0; t < NRT; ++t) acc[t] = mfma16(tr_frag16(sR, 0, t * 16, fr, fg), lb, acc[t]);
     }
     const int i = i0 + w * 16 + fr;
+    if (inv_gscale) scale *= inv_gscale[0];        // undo the (batch-uniform) fp16 gradient scale
     if (i < ncl) {
 #pragma unroll
         for (int t = 0; t < NRT; ++t)
@@ -101,11 +102,11 @@ __global__ __launch_bounds__(256) void lora_wgrad_mfma_kernel(const bf16* __rest
 }  // namespace
 
 // L: wide operand [M, ncl]; Rm: rank operand [M, ncr <= 64]; out (+)= scale * L^T Rm  (or its transpose)
-void k_lora_wgrad(const bf16* L, int ldl, int ncl, const bf16* Rm, int ldr, int ncr, int M, float scale, float* out,
-                  int ldo, int transpose_out, float* /*scratch*/, hipStream_t s) {
+void k_lora_wgrad(const h16* L, int ldl, int ncl, const h16* Rm, int ldr, int ncr, int M, float scale, float* out,
+                  int ldo, int transpose_out, const float* inv_gscale, hipStream_t s) {
     ProfScope prof_("lora_wgrad_mfma_kernel", 2.0 * M * (double)ncl * ncr, (double)M * ncl * 2.0, s);
     dim3 grid((ncl + 63) / 64, (M + MCHUNK - 1) / MCHUNK);
-    if (ncr <= 16) hipLaunchKernelGGL((lora_wgrad_mfma_kernel<1>), grid, dim3(256), 0, s, L, ldl, ncl, Rm, ldr, ncr, M, scale, out, ldo, transpose_out);
-    else if (ncr <= 32) hipLaunchKernelGGL((lora_wgrad_mfma_kernel<2>), grid, dim3(256), 0, s, L, ldl, ncl, Rm, ldr, ncr, M, scale, out, ldo, transpose_out);
-    else hipLaunchKernelGGL((lora_wgrad_mfma_kernel<4>), grid, dim3(256), 0, s, L, ldl, ncl, Rm, ldr, ncr, M, scale, out, ldo, transpose_out);
+    if (ncr <= 16) hipLaunchKernelGGL((lora_wgrad_mfma_kernel<1>), grid, dim3(256), 0, s, L, ldl, ncl, Rm, ldr, ncr, M, scale, out, ldo, transpose_out, inv_gscale);
+    else if (ncr <= 32) hipLaunchKernelGGL((lora_wgrad_mfma_kernel<2>), grid, dim3(256), 0, s, L, ldl, ncl, Rm, ldr, ncr, M, scale, out, ldo, transpose_out, inv_gscale);
+    else hipLaunchKernelGGL((lora_wgrad_mfma_kernel<4>), grid, dim3(256), 0, s, L, ldl, ncl, Rm, ldr, ncr, M, scale, out, ldo, transpose_out, inv_gscale);
 }

@@ -1,0 +1,120 @@
+// Model handle, packed weights and workspace of libvitlora_hip.so, shared by the API file
+// (vitlora.hip: 16-bit operand path) and the fp32 parity path (vitlora_f32.hip).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/vitlora.h"
+#include "kernels.h"
+
+enum { LQKV = 0, LO = 1, LFC1 = 2, LFC2 = 3 };
+static const uint32_t kTargetBits[6] = {VL_T_Q, VL_T_K, VL_T_V, VL_T_O, VL_T_FC1, VL_T_FC2};
+
+struct Slot {           // one adapted module inside a fused projection
+    int target_idx;     // 0..5 (q,k,v,o,fc1,fc2)
+    int row_off;        // first output row of the module inside the fused projection
+    int out, in;
+    int ext_off;        // first column of its r slots inside the K extension
+    int64_t a_off, b_off;  // offsets into the flat parameter buffer
+};
+
+struct Linear {
+    int out = 0, in = 0;
+    h16* W = nullptr;     // [out, in]
+    h16* WT = nullptr;    // [in, out]
+    float* bias = nullptr;
+    float* Wf32 = nullptr;   // fp32 master: kept when adapters may be merged into W, and in fp32 mode
+    float* Wrun = nullptr;   // fp32 mode: the operand the GEMMs read (= Wf32, or the merged copy W + s B A)
+    int kext = 0;
+    std::vector<Slot> slots;
+    h16* Ad = nullptr;    // [kext, in]   t = x Ad^T
+    h16* Bu = nullptr;    // [out, kext]  y += t Bu^T        (scaling folded in)
+    h16* Bd = nullptr;    // [kext, out]  u = dy Bd^T
+    h16* Au = nullptr;    // [in, kext]   dx += u Au^T       (scaling folded in)
+};
+
+struct Layer {
+    Linear lin[4];
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+};
+
+struct Workspace {
+    char* base = nullptr;
+    size_t bytes = 0;
+    int max_batch = 0, train = 0;
+    int64_t Mpad = 0, Mppad = 0;
+    h16* patches;
+    std::vector<float*> xs;          // 2L+1 residual-stream snapshots [Mpad, D]
+    std::vector<float*> mean, rstd;  // 2L
+    std::vector<h16*> h1, h2, a;     // per layer in train mode, shared otherwise
+    std::vector<h16*> qkv, ctx, z;
+    std::vector<float*> lse;
+    std::vector<h16*> t[4];          // LoRA down outputs (per layer in train mode)
+    float *xhat, *xf, *rstd_f, *logits, *dlogits, *loss, *loss_img;
+    float *gscale, *inv_gscale;      // per-image power-of-two gradient scale of the 16-bit backward (and its inverse)
+    float* dres[2];
+    h16 *dres_h, *dh, *dctx, *dqkv, *dz, *u;
+    h16* xd;                         // train mode: dropout(x) of the current LoRA branch / dgrad temporary [Mpad, MLP]
+    float* grad_img;                 // [max_batch, 3, S, S] for vl_pgd_attack
+    // persistent staging of vl_pgd_attack: the captured graph only ever sees these addresses
+    float *stage_x0, *stage_adv;
+    int64_t* stage_labels;
+    // ---- fp32 parity mode (vitlora_f32.hip): every activation fp32 ----
+    float* f_patches;
+    std::vector<float*> f_h1, f_h2, f_a, f_qkv, f_ctx, f_z;
+    std::vector<float*> f_t[4];
+    float *f_dh, *f_dctx, *f_dqkv, *f_dz, *f_u, *f_xd, *f_tmp;
+};
+
+struct GraphEntry {
+    int B; float eps, alpha;
+    hipGraphExec_t exec;
+};
+
+struct vl_model {
+    vl_config cfg;
+    int D, L, H, MLP, S, P, G, NP, T, C, PK;   // PK = 3*P*P
+    int r = 0;
+    float scaling = 0.f;
+    int f32 = 0;                                // cfg.precision == VL_PREC_F32
+    int device = 0;
+    // embeddings / head
+    h16 *Wpe = nullptr, *WpeT = nullptr;
+    float* Wpe_f32 = nullptr;                   // fp32 mode
+    float *bpe = nullptr, *cls = nullptr, *pos = nullptr, *lnf_g = nullptr, *lnf_b = nullptr;
+    std::vector<Layer> layers;
+    std::vector<void*> allocs;
+    // flat trainable parameters: [layer][target]{A,B} ..., classifier W, classifier b
+    float* flat = nullptr;
+    int64_t flat_n = 0, cls_w_off = 0, cls_b_off = 0;
+    int dirty = 1;                              // flat parameters changed since the last vl_lora_commit
+    Workspace ws;
+    // state of the last forward
+    int cur_B = 0, cur_M = 0, cur_norm = 0, cur_train = 0, have_loss = 0;
+    uint64_t drop_seed = 0x5eed, drop_base = 0x5eed, drop_calls = 0;   // LoRA dropout: seed of the last train-mode forward
+    // PGD graph cache (one executable graph per (batch, eps, alpha); staging buffers make it pointer-independent)
+    std::vector<GraphEntry> graphs;
+    hipStream_t cap_stream = nullptr;
+    int64_t n_captures = 0, n_commits = 0;
+    int use_graph = 1;
+    int resid_epi = 0;    // VITLORA_RESID=epilogue: residual add in the o / fc2 GEMM epilogue (fp32 read-modify-write), for A/B runs
+    int plan_batch = 0, plan_train = 0;
+    int* err_flag = nullptr;                    // pinned host word written by kernels (bad label, ...), read at API entry
+    float mean[3] = {0.485f, 0.456f, 0.406f};   // get_normalization, Utils.py:92-93
+    float stdv[3] = {0.229f, 0.224f, 0.225f};
+};
+
+// helpers defined in vitlora.hip
+int vl_fail(int code, const char* fmt, ...);
+#define HIPCHK(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return vl_fail(VL_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+bool vl_drop_on(const vl_model* m);
+
+// fp32 parity path (vitlora_f32.hip)
+size_t f32_carve(vl_model* m, int B, int train, char* base, size_t off0);
+int f32_forward(vl_model* m, const float* x, int B, int normalise, int train, hipStream_t s);
+int f32_backward(vl_model* m, float* grad_x, float* flat_grad, hipStream_t s);
+int f32_init(int device);     // kernel attributes; 0 = ok

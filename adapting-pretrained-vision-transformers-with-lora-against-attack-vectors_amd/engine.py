@@ -13,7 +13,7 @@ from typing import Dict, Iterable, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import VL_T, VLConfig, check
+from ._lib import VL_PREC, VL_T, VLConfig, check
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)     # get_normalization, Utils.py:92-93
 IMAGENET_STD = (0.229, 0.224, 0.225)
@@ -91,7 +91,10 @@ def _view_f32(ptr: int, shape, device) -> torch.Tensor:
 
 
 class Engine:
-    def __init__(self, arch: ArchConfig, lora: Optional[LoraSpec] = None, device="cuda:0"):
+    """precision: "f16" (default; fp16 operands, fp32 accumulation and residual stream -- the MFMA-rate path) or
+    "f32" (every operand and activation fp32: the parity mode held to 1e-3 against the reference's CPU path)."""
+
+    def __init__(self, arch: ArchConfig, lora: Optional[LoraSpec] = None, device="cuda:0", precision: str = "f16"):
         if not torch.cuda.is_available():
             raise _lib.VitLoraError("no GPU visible: the vitlora engine runs on MI355X only (no CPU fallback)")
         self.lib = _lib.load()
@@ -109,6 +112,10 @@ class Engine:
         cfg.lora_r = self.lora.r if tb else 0
         cfg.lora_alpha, cfg.lora_dropout = float(self.lora.alpha), float(self.lora.dropout)
         cfg.lora_targets, cfg.lora_merged = tb, int(self.lora.merged)
+        if precision not in VL_PREC:
+            raise ValueError(f"precision must be one of {sorted(VL_PREC)}")
+        cfg.precision = VL_PREC[precision]
+        self.precision = "f32" if cfg.precision else "f16"
         h = C.c_void_p()
         check(self.lib.vl_create(C.byref(cfg), C.byref(h)), "vl_create")
         self.h = h
@@ -171,7 +178,18 @@ class Engine:
         return _view_f32(p.value, shape, self.device)
 
     def commit(self):
+        """Explicit vl_lora_commit.  Not needed for correctness: the library commits by itself before a forward /
+        attack whenever the parameters changed (param(), adam_step() and mark_dirty() tell it so)."""
         check(self.lib.vl_lora_commit(self.h, self._stream()), "vl_lora_commit")
+
+    def mark_dirty(self):
+        """The flat parameters were written through a view kept from earlier (self.flat, a broadcast, ...)."""
+        check(self.lib.vl_params_changed(self.h), "vl_params_changed")
+
+    def counter(self, what: str) -> int:
+        v = C.c_int64()
+        check(self.lib.vl_debug_counter(self.h, what.encode(), C.byref(v)), "vl_debug_counter")
+        return int(v.value)
 
     def set_normalization(self, mean, std):
         key = (tuple(float(v) for v in mean), tuple(float(v) for v in std))
@@ -298,7 +316,7 @@ class Engine:
         if dt.value == 0:
             return _view_f32(p.value, (n.value,), self.device)
         v = torch.as_tensor(_DevView(p.value, (n.value,), "<i2"), device=self.device)
-        return v.view(torch.bfloat16)
+        return v.view(torch.float16)
 
     def _check_images(self, x: torch.Tensor) -> torch.Tensor:
         S = self.arch.image_size

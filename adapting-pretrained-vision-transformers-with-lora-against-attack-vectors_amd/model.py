@@ -62,8 +62,10 @@ class _ViTFunction(torch.autograd.Function):
 class ViTForImageClassification(torch.nn.Module):
     """Drop-in for the object `create_vit_model` returns (Utils.py:84-90)."""
 
-    def __init__(self, arch: Optional[ArchConfig] = None, lora: Optional[LoraSpec] = None, device=None):
+    def __init__(self, arch: Optional[ArchConfig] = None, lora: Optional[LoraSpec] = None, device=None,
+                 precision: str = "f16"):
         super().__init__()
+        self.precision = precision
         self.arch = arch or ArchConfig()
         self.lora_spec = lora or LoraSpec()
         self._device = torch.device(device) if device is not None else None
@@ -79,11 +81,10 @@ class ViTForImageClassification(torch.nn.Module):
     def _engine(self) -> Engine:
         if self._eng is None:
             dev = self._device or torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
-            self._eng = Engine(self.arch, self.lora_spec, device=dev)
+            self._eng = Engine(self.arch, self.lora_spec, device=dev, precision=self.precision)
             if self._host_sd:
                 self._eng.load_state_dict(self._host_sd, strict=False)
             self._flat_param = torch.nn.Parameter(self._eng.flat, requires_grad=True)
-            self._committed = False
         return self._eng
 
     def to(self, device=None, *args, **kwargs):
@@ -114,13 +115,13 @@ class ViTForImageClassification(torch.nn.Module):
         yield (prefix + "trainable_flat", self.trainable_flat())
 
     def commit(self):
-        """Re-derive the bf16 GEMM operands after the flat parameters changed (optimizer step,
-        adapter load).  Called automatically before a forward when marked dirty."""
+        """Re-derive the fp16 GEMM operands now.  Optional: the library tracks parameter changes itself and
+        commits before the next forward / attack (vl_params_changed, include/vitlora.h)."""
         self._engine().commit()
-        self._committed = True
 
     def mark_dirty(self):
-        self._committed = False
+        """Parameters were written through the flat Parameter (optimizer, broadcast, in-place copy)."""
+        self._engine().mark_dirty()
 
     # ---- state dict -----------------------------------------------------------------------
     def load_state_dict(self, state_dict, strict: bool = True):
@@ -149,8 +150,6 @@ class ViTForImageClassification(torch.nn.Module):
         if x is None:
             raise ValueError("pixel_values is required")
         eng = self._engine()
-        if not getattr(self, "_committed", False) and self.lora_spec.r > 0:
-            self.commit()
         x = x.to(device=eng.device, dtype=torch.float32)
         logits = _ViTFunction.apply(x, self._flat_param, self, bool(normalise))
         return SimpleNamespace(logits=logits)
@@ -167,11 +166,12 @@ class LogitsModel(torch.nn.Module):
         return get_model_output(self.model(x))
 
 
-def create_vit_model(num_classes: int, pretrained: bool = True, arch: Optional[ArchConfig] = None, device=None):
+def create_vit_model(num_classes: int, pretrained: bool = True, arch: Optional[ArchConfig] = None, device=None,
+                     precision: str = "f16"):
     """ViT-B/16 classifier with `num_classes` labels (Utils.py:84-90).  The reference fetches
     'google/vit-base-patch16-224' from the hub; here the architecture is built locally and the
     weights come from `load_state_dict` (the reference's very next step, whitebox_attacks.py:94)."""
     a = arch or ArchConfig()
     a = ArchConfig(image_size=a.image_size, patch_size=a.patch_size, hidden=a.hidden, layers=a.layers,
                    heads=a.heads, mlp=a.mlp, num_labels=int(num_classes), ln_eps=a.ln_eps)
-    return ViTForImageClassification(a, device=device)
+    return ViTForImageClassification(a, device=device, precision=precision)

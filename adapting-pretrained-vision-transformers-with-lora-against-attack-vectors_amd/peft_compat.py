@@ -77,7 +77,7 @@ class PeftModel(torch.nn.Module):
     def _attach(base: ViTForImageClassification, config: LoraConfig, init_B_zero=True, seed: Optional[int] = None):
         spec = LoraSpec(r=int(config.r), alpha=float(config.lora_alpha), dropout=float(config.lora_dropout),
                         targets=config.targets(), merged=False)
-        vit = ViTForImageClassification(base.arch, spec, device=base._device)
+        vit = ViTForImageClassification(base.arch, spec, device=base._device, precision=base.precision)
         vit.load_state_dict(base.state_dict(), strict=False)
         eng = vit._engine()
         g = torch.Generator().manual_seed(seed) if seed is not None else None
@@ -200,7 +200,7 @@ class PeftModel(torch.nn.Module):
                 check(eng.lib.vl_merge_weight(eng.h, i, VL_T[t], C.c_void_p(W.data_ptr()), C.c_void_p(W.data_ptr()),
                                               eng._stream()), "vl_merge_weight")
                 sd[key] = W.cpu()
-        out = ViTForImageClassification(vit.arch, LoraSpec(), device=vit._device)
+        out = ViTForImageClassification(vit.arch, LoraSpec(), device=vit._device, precision=vit.precision)
         out.load_state_dict(sd, strict=False)
         out.train(self.training)
         return out

@@ -40,6 +40,9 @@ extern "C" {
 #define VL_T_FC1 16u   /* intermediate.dense     */
 #define VL_T_FC2 32u   /* output.dense           */
 
+#define VL_PREC_F16 0
+#define VL_PREC_F32 1
+
 typedef struct vl_config {
     /* architecture: HF ViTConfig as built by create_vit_model, Utils.py:84-90 */
     int32_t image_size;   /* 224 */
@@ -58,7 +61,10 @@ typedef struct vl_config {
     int32_t lora_merged;  /* 0: rank-r update fused into the GEMMs as extra K tiles;
                              1: W' = W + s*B*A folded at vl_lora_commit (merge_and_unload,
                                 eval_compose.py:110) */
-    int32_t reserved[4];
+    int32_t precision;    /* VL_PREC_F16 (default): fp16 operands, fp32 accumulation / residual stream (MFMA rate);
+                             VL_PREC_F32: every operand and activation fp32 (v_mfma_f32_16x16x4_f32), the
+                             parity mode held to 1e-3 against the reference's fp32 CPU path */
+    int32_t reserved[3];
 } vl_config;
 
 typedef struct vl_model vl_model;
@@ -86,6 +92,12 @@ int vl_param_flat(vl_model* m, float** ptr, int64_t* numel);
  * adapter, after an optimiser step, or to merge).  PeftModel.from_pretrained /
  * merge_and_unload (train_loras.py:419, eval_compose.py:108-110). */
 int vl_lora_commit(vl_model* m, void* stream);
+/* The library tracks whether the flat parameters changed since the last commit: vl_param_tensor /
+ * vl_param_flat hand out writable pointers and mark the handle dirty, vl_adam_step marks the model
+ * whose flat buffer it updates, and a caller that writes through a pointer it kept calls
+ * vl_params_changed.  vl_forward / vl_pgd_attack commit by themselves when the handle is dirty, so a
+ * stale adapter can never be attacked or trained (peft re-reads its Parameters on every forward). */
+int vl_params_changed(vl_model* m);
 
 /* merge_and_unload for one adapted module (eval_compose.py:102-114): W_out = W_in + (alpha/r) B A,
  * fp32 [out,in] device buffers of the caller (may alias); A, B are the module's current adapters. */
@@ -182,7 +194,9 @@ int vl_profile_report(char* buf, size_t cap);
  * launches timed with HIP events; epi = GemmEpilogue of csrc/gemm.h (+100: all rows stored to row 0). */
 int vl_bench_gemm(int M, int N, int K1, int K2, int epi, int bn, int iters, float* ms_out);
 
-/* Introspection for tests / profiling. */
+/* Introspection for tests / profiling.  vl_debug_counter: "graph_captures" = PGD graphs captured so far,
+ * "commits" = vl_lora_commit executions, "dirty" = 1 if parameters changed since the last commit. */
+int vl_debug_counter(vl_model* m, const char* what, int64_t* value);
 int vl_debug_tensor(vl_model* m, const char* what, int layer, void** ptr, int64_t* numel, int* dtype);
 
 #ifdef __cplusplus

@@ -32,10 +32,11 @@ Pinning status (see DESIGN.md "Oracle"):
     here); the LoRA trainable-parameter counts printed in infLora.ipynb:163,919
     are the only reference-held known answers and are tested.
 
-``sim_bf16=True`` inserts bf16 round-trips at exactly the places where the HIP
-path stores bf16 (GEMM operands, saved activations, gradients between kernels),
-so the kernels can be held to a much tighter tolerance than the fp32-vs-bf16
-precision gap would allow.
+``sim16=True`` inserts fp16 round-trips (``SIM_DTYPE``) at the places where the HIP
+path stores 16-bit values (GEMM operands, saved activations, gradients between
+kernels), so the kernels can be held to a much tighter tolerance than the
+fp32-vs-fp16 precision gap would allow.  ``sim16`` may also be a set of site names
+(``SITES``) to round only there: tools/error_budget.py uses it to price each hop.
 """
 from __future__ import annotations
 
@@ -183,39 +184,103 @@ def count_parameters(cfg: OracleConfig, lora: Optional[OracleLora]) -> Tuple[int
 # ----------------------------------------------------------------------------
 # forward
 # ----------------------------------------------------------------------------
+SIM_DTYPE = torch.float16      # the 16-bit storage type of the HIP path (tools/error_budget.py also tries bfloat16)
+
+
 class _RoundBF16(torch.autograd.Function):
-    """bf16 round trip applied to the value in forward AND to the gradient in
-    backward: models a tensor (and its gradient) that the HIP path stores as bf16."""
+    """16-bit round trip applied to the value in forward AND to the gradient in
+    backward: models a tensor (and its gradient) that the HIP path stores in 16 bits."""
 
     @staticmethod
     def forward(ctx, x):
-        return x.to(torch.bfloat16).to(torch.float32)
+        return x.to(SIM_DTYPE).to(torch.float32)
 
     @staticmethod
     def backward(ctx, g):
-        return g.to(torch.bfloat16).to(torch.float32)
+        return g.to(SIM_DTYPE).to(torch.float32)
 
 
 class _RoundFwdOnly(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
-        return x.to(torch.bfloat16).to(torch.float32)
+        return x.to(SIM_DTYPE).to(torch.float32)
 
     @staticmethod
     def backward(ctx, g):
         return g
 
 
-def _rb(x, on):          # value and gradient rounded
-    return _RoundBF16.apply(x) if on else x
+class _RoundBwdOnly(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(SIM_DTYPE).to(torch.float32)
 
 
-def _rf(x, on):          # value rounded, gradient passes
-    return _RoundFwdOnly.apply(x) if on else x
+# ``sim`` is False (fp32 arithmetic), True (every site rounded) or a collection of site names:
+# only those sites are rounded (error-budget experiments, tools/error_budget.py).  A name with the
+# suffix ":f" / ":b" rounds only the forward value / only the gradient at that site.
+SITES = ("patches", "h", "qkv", "probs", "ctx", "delta", "act", "gelu_prime", "dz", "t", "weights", "lora_w")
 
 
-def _wq(w, on):          # frozen weight as the kernels hold it
-    return w.to(torch.bfloat16).to(torch.float32) if on else w
+def _on(sim, site):
+    if isinstance(sim, bool):
+        return (sim, sim)
+    return (site in sim or site + ":f" in sim, site in sim or site + ":b" in sim)
+
+
+def _rb(x, sim, site="all"):          # value and gradient rounded
+    f, b = _on(sim, site)
+    if f and b:
+        return _RoundBF16.apply(x)
+    if f:
+        return _RoundFwdOnly.apply(x)
+    if b:
+        return _RoundBwdOnly.apply(x)
+    return x
+
+
+def _rf(x, sim, site="lora_w"):       # value rounded, gradient passes
+    return _RoundFwdOnly.apply(x) if _on(sim, site)[0] else x
+
+
+def _wq(w, sim):          # frozen weight as the kernels hold it
+    return w.to(SIM_DTYPE).to(torch.float32) if _on(sim, "weights")[0] else w
+
+
+class _GeluSim(torch.autograd.Function):
+    """exact-erf GELU as the HIP fc1 epilogue / fc2-dgrad epilogue pair computes it: the forward
+    keeps a = gelu(z) and g' = gelu'(z) (each rounded to 16 bits when its site is on); the backward is
+    dz = da * g' with da still in the fp32 accumulator, rounded once (site "dz")."""
+
+    @staticmethod
+    def forward(ctx, z, r_act, r_gp, r_dz):
+        cdf = 0.5 * (1.0 + torch.erf(z * 0.7071067811865476))
+        pdf = 0.3989422804014327 * torch.exp(-0.5 * z * z)
+        gp = cdf + z * pdf
+        if r_gp:
+            gp = gp.to(SIM_DTYPE).to(torch.float32)
+        ctx.save_for_backward(gp)
+        ctx.r_dz = r_dz
+        a = z * cdf
+        return a.to(SIM_DTYPE).to(torch.float32) if r_act else a
+
+    @staticmethod
+    def backward(ctx, da):
+        (gp,) = ctx.saved_tensors
+        dz = da * gp
+        if ctx.r_dz:
+            dz = dz.to(SIM_DTYPE).to(torch.float32)
+        return dz, None, None, None
+
+
+def gelu_sim(z, sim):
+    if sim is False:
+        return F.gelu(z)
+    return _GeluSim.apply(z, _on(sim, "act")[0], _on(sim, "gelu_prime")[0], _on(sim, "dz")[0])
 
 
 def lora_linear(x, W, b, ab, scaling, sim=False, drop_mask=None):
@@ -225,25 +290,25 @@ def lora_linear(x, W, b, ab, scaling, sim=False, drop_mask=None):
     if ab is not None:
         A, B = ab
         xd = x if drop_mask is None else x * drop_mask
-        t = _rb(F.linear(xd, _rf(A, sim)), sim)
+        t = _rb(F.linear(xd, _rf(A, sim)), sim, "t")
         y = y + F.linear(t, _rf(B * scaling, sim))
     return y
 
 
 def vit_forward(w: Dict[str, torch.Tensor], cfg: OracleConfig, x_norm: torch.Tensor,
-                lora: Optional[OracleLora] = None, sim_bf16: bool = False,
+                lora: Optional[OracleLora] = None, sim16: bool = False,
                 return_hidden: bool = False, trace: Optional[dict] = None,
                 drop_masks: Optional[dict] = None):
     """logits [B, C] from already-normalised pixels [B, 3, H, W].  ``trace`` (a dict)
     receives the intermediate tensors the HIP path exposes through vl_debug_tensor."""
-    sim = sim_bf16
+    sim = sim16
     B = x_norm.shape[0]
     D, H, dh, N = cfg.hidden, cfg.heads, cfg.head_dim, cfg.tokens
     P = cfg.patch_size
     # K2 patchify + embed (Conv2d k=s=P == GEMM over flattened (c,ph,pw) patches)
     g = cfg.image_size // P
     patches = x_norm.reshape(B, 3, g, P, g, P).permute(0, 2, 4, 1, 3, 5).reshape(B, g * g, 3 * P * P)
-    patches = _rb(patches, sim)
+    patches = _rb(patches, sim, "patches")
     Wpe = w["vit.embeddings.patch_embeddings.projection.weight"].reshape(D, 3 * P * P)
     emb = F.linear(patches, _wq(Wpe, sim), w["vit.embeddings.patch_embeddings.projection.bias"])
     x = torch.cat([w["vit.embeddings.cls_token"].expand(B, -1, -1), emb], dim=1)
@@ -268,23 +333,23 @@ def vit_forward(w: Dict[str, torch.Tensor], cfg: OracleConfig, x_norm: torch.Ten
             return lora_linear(inp, w[k + ".weight"], w[k + ".bias"], ab(i, short), sc, sim, dm)
 
         h = _rb(F.layer_norm(x, (D,), w[p + "layernorm_before.weight"],
-                             w[p + "layernorm_before.bias"], cfg.ln_eps), sim)
-        q = _rb(lin("q", h), sim).view(B, N, H, dh).transpose(1, 2)
-        k_ = _rb(lin("k", h), sim).view(B, N, H, dh).transpose(1, 2)
-        v = _rb(lin("v", h), sim).view(B, N, H, dh).transpose(1, 2)
+                             w[p + "layernorm_before.bias"], cfg.ln_eps), sim, "h")
+        q = _rb(lin("q", h), sim, "qkv").view(B, N, H, dh).transpose(1, 2)
+        k_ = _rb(lin("k", h), sim, "qkv").view(B, N, H, dh).transpose(1, 2)
+        v = _rb(lin("v", h), sim, "qkv").view(B, N, H, dh).transpose(1, 2)
         s = torch.matmul(q, k_.transpose(2, 3)) * (dh ** -0.5)
-        pr = _rb(torch.softmax(s, dim=-1), sim)
-        ctx = _rb(torch.matmul(pr, v).transpose(1, 2).reshape(B, N, D), sim)
+        pr = _rb(torch.softmax(s, dim=-1), sim, "probs")
+        ctx = _rb(torch.matmul(pr, v).transpose(1, 2).reshape(B, N, D), sim, "ctx")
         if trace is not None:
             trace[f"qkv{i}"] = torch.cat([t_.transpose(1, 2).reshape(B, N, D) for t_ in (q, k_, v)], dim=-1).detach()
             trace[f"ctx{i}"] = ctx.detach()
-        x = x + _rb(lin("o", ctx), sim)       # projection output held as bf16, added by the next LN pass
+        x = x + _rb(lin("o", ctx), sim, "delta")       # projection output held in 16 bits, added by the next LN pass
         if trace is not None:
             trace[f"xs{2 * i + 1}"] = x.detach()
         h2 = _rb(F.layer_norm(x, (D,), w[p + "layernorm_after.weight"],
-                              w[p + "layernorm_after.bias"], cfg.ln_eps), sim)
-        a = _rb(F.gelu(lin("fc1", h2)), sim)          # exact erf GELU (hidden_act="gelu")
-        x = x + _rb(lin("fc2", a), sim)
+                              w[p + "layernorm_after.bias"], cfg.ln_eps), sim, "h")
+        a = gelu_sim(lin("fc1", h2), sim)          # exact erf GELU (hidden_act="gelu")
+        x = x + _rb(lin("fc2", a), sim, "delta")
         if trace is not None:
             trace[f"xs{2 * i + 2}"] = x.detach()
     xf = F.layer_norm(x[:, 0], (D,), w["vit.layernorm.weight"], w["vit.layernorm.bias"], cfg.ln_eps)
@@ -298,11 +363,11 @@ def normalise(x, mean=IMAGENET_MEAN, std=IMAGENET_STD):
     return (x - m) / s
 
 
-def loss_and_input_grad(w, cfg, x01, labels, lora=None, sim_bf16=False, normalised=False):
+def loss_and_input_grad(w, cfg, x01, labels, lora=None, sim16=False, normalised=False):
     """(mean CE loss, dLoss/dx, logits) with x in [0,1] pixel space (normalisation
     inside) -- whitebox_attacks.py:24-30 -- or in model space when normalised=True."""
     x = x01.clone().detach().requires_grad_(True)
-    logits = vit_forward(w, cfg, x if normalised else normalise(x), lora, sim_bf16)
+    logits = vit_forward(w, cfg, x if normalised else normalise(x), lora, sim16)
     loss = F.cross_entropy(logits, labels)
     (gx,) = torch.autograd.grad(loss, x)
     return loss.detach(), gx, logits.detach()
@@ -318,13 +383,13 @@ def pgd_step(adv, x0, grad, eps, alpha, lo=0.0, hi=1.0):
     return torch.clamp(x0 + delta, min=lo, max=hi)
 
 
-def fgsm(w, cfg, x01, labels, eps, lora=None, sim_bf16=False):
+def fgsm(w, cfg, x01, labels, eps, lora=None, sim16=False):
     """whitebox_attacks.py:22-38: clamp(x + eps*sign(dCE/dx), 0, 1)."""
-    _, g, _ = loss_and_input_grad(w, cfg, x01, labels, lora, sim_bf16)
+    _, g, _ = loss_and_input_grad(w, cfg, x01, labels, lora, sim16)
     return torch.clamp(x01 + eps * torch.sign(g), 0.0, 1.0)
 
 
-def pgd(w, cfg, x01, labels, eps, alpha, steps, lora=None, noise=None, sim_bf16=False,
+def pgd(w, cfg, x01, labels, eps, alpha, steps, lora=None, noise=None, sim16=False,
         return_trace=False):
     """Canonical torchattacks.PGD.forward.  ``noise`` in [-1,1] is the
     supplied random start (scaled by eps); None = random_start False."""
@@ -333,7 +398,7 @@ def pgd(w, cfg, x01, labels, eps, alpha, steps, lora=None, noise=None, sim_bf16=
         adv = torch.clamp(adv + eps * noise, 0.0, 1.0)
     trace = []
     for _ in range(steps):
-        loss, g, _ = loss_and_input_grad(w, cfg, adv, labels, lora, sim_bf16)
+        loss, g, _ = loss_and_input_grad(w, cfg, adv, labels, lora, sim16)
         adv = pgd_step(adv, x01, g, eps, alpha)
         if return_trace:
             trace.append((loss.item(), g))
@@ -361,7 +426,7 @@ def pgd_torchattacks_compat(w, cfg, x01, labels, eps, alpha, steps, lora=None, n
 # ----------------------------------------------------------------------------
 # LoRA training step, Adam, image quantisation
 # ----------------------------------------------------------------------------
-def lora_train_grads(w, cfg, x_norm, labels, lora: OracleLora, sim_bf16=False,
+def lora_train_grads(w, cfg, x_norm, labels, lora: OracleLora, sim16=False,
                      train_classifier=True, drop_masks=None):
     """Gradients of mean CE w.r.t. every LoRA A, B (and the classifier, which peft
     keeps trainable for SEQ_CLS) -- the backward of train_loras.py:310-314."""
@@ -378,7 +443,7 @@ def lora_train_grads(w, cfg, x_norm, labels, lora: OracleLora, sim_bf16=False,
         w2["classifier.bias"] = w["classifier.bias"].clone().requires_grad_(True)
         leaves[("cls", "weight")] = w2["classifier.weight"]
         leaves[("cls", "bias")] = w2["classifier.bias"]
-    logits = vit_forward(w2, cfg, x_norm, lr, sim_bf16, drop_masks=drop_masks)
+    logits = vit_forward(w2, cfg, x_norm, lr, sim16, drop_masks=drop_masks)
     loss = F.cross_entropy(logits, labels)
     grads = torch.autograd.grad(loss, list(leaves.values()))
     return loss.detach(), logits.detach(), dict(zip(leaves.keys(), grads))

@@ -36,14 +36,14 @@ def make_case(image_size=64, hidden=128, layers=2, heads=2, mlp=256, num_labels=
     return cfg, w, lora, x, y
 
 
-def make_engine(cfg, w, lora=None, merged=False, dropout=0.0):
+def make_engine(cfg, w, lora=None, merged=False, dropout=0.0, precision="f16"):
     P = pkg()
     arch = P.ArchConfig(image_size=cfg.image_size, patch_size=cfg.patch_size, hidden=cfg.hidden, layers=cfg.layers,
                         heads=cfg.heads, mlp=cfg.mlp, num_labels=cfg.num_labels, ln_eps=cfg.ln_eps)
     spec = None
     if lora is not None:
         spec = P.LoraSpec(r=lora.r, alpha=lora.alpha, dropout=dropout, targets=tuple(lora.targets), merged=merged)
-    eng = P.Engine(arch, spec)
+    eng = P.Engine(arch, spec, precision=precision)
     eng.load_state_dict(w)
     if lora is not None:
         for (i, t), (A, B) in lora.ab.items():

@@ -1,6 +1,6 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded
 inputs.  Two oracles modes are used:
-  * sim_bf16 = the oracle with bf16 round trips where the kernels store bf16 -> tight
+  * sim16 = the oracle with bf16 round trips where the kernels store bf16 -> tight
     tolerances that check the kernels' logic (indexing, masking, softmax, LoRA fusion);
   * fp32     = the reference arithmetic -> the north-star bf16 tolerance (1e-2 relative).
 """
@@ -18,7 +18,7 @@ TOL_FP32 = 1e-2     # north_star: 1e-2 relative for the bf16 path vs the fp32 re
 
 def _trace(cfg, w, lora, x_norm, sim):
     tr = {}
-    logits = O.vit_forward(w, cfg, x_norm, lora, sim_bf16=sim, trace=tr)
+    logits = O.vit_forward(w, cfg, x_norm, lora, sim16=sim, trace=tr)
     tr["logits"] = logits
     return tr
 
@@ -61,7 +61,7 @@ def test_loss_and_input_grad(image_size, batch, with_lora):
     loss = eng.loss_ce(y.cuda())
     gx, _ = eng.backward(True, False, tuple(x.shape))
     torch.cuda.synchronize()
-    l_sim, g_sim, _ = O.loss_and_input_grad(w, cfg, x, y, lora, sim_bf16=True)
+    l_sim, g_sim, _ = O.loss_and_input_grad(w, cfg, x, y, lora, sim16=True)
     l_ref, g_ref, lg_ref = O.loss_and_input_grad(w, cfg, x, y, lora)
     assert abs(loss.item() - l_sim.item()) < 2e-3 * max(1.0, abs(l_sim.item()))
     e_sim, e_ref = rel_l2(gx.cpu(), g_sim), rel_l2(gx.cpu(), g_ref)
@@ -85,7 +85,7 @@ def test_lora_down_fusion_variants(r, targets):
     eng.loss_ce(y.cuda())
     gx, _ = eng.backward(True, False, tuple(x.shape))
     torch.cuda.synchronize()
-    _, g_sim, lg_sim = O.loss_and_input_grad(w, cfg, x, y, lora, sim_bf16=True)
+    _, g_sim, lg_sim = O.loss_and_input_grad(w, cfg, x, y, lora, sim16=True)
     _, g_ref, lg_ref = O.loss_and_input_grad(w, cfg, x, y, lora)
     assert rel_l2(logits.cpu(), lg_sim) < TOL_SIM_LOGITS
     assert rel_l2(logits.cpu(), lg_ref) < TOL_FP32
@@ -230,7 +230,7 @@ def test_lora_train_grads():
     _, gp = eng.backward(False, True)
     torch.cuda.synchronize()
     l_ref, lg_ref, grads = O.lora_train_grads(w, cfg, xn, y, lora)
-    l_sim, _, grads_sim = O.lora_train_grads(w, cfg, xn, y, lora, sim_bf16=True)
+    l_sim, _, grads_sim = O.lora_train_grads(w, cfg, xn, y, lora, sim16=True)
     assert abs(loss.item() - l_ref.item()) < 1e-2 * abs(l_ref.item())
     # walk the flat layout: same order as the library (layer, target) -> A, B ; classifier
     flat = eng.flat
