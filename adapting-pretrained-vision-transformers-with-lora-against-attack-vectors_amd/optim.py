@@ -1,7 +1,7 @@
 """Optimizer + data-parallel glue of the LoRA train step (train_loras.py:284, 308, 314-315).
 
 `Adam` keeps torch.optim.Adam's constructor / zero_grad / step surface but updates the model's
-single flat fp32 parameter with ONE fused kernel (vl_adam_step) and re-derives the bf16 GEMM
+single flat fp32 parameter with ONE fused kernel (vl_adam_step) and re-derives the fp16 GEMM
 operands afterwards (vl_lora_commit).  With a process group, `step()` first sums the flat
 gradient over ranks with ONE all-reduce (RCCL over xGMI on MI355X; gloo in CPU tests) and
 divides by the world size: local losses are means over the local shard.
@@ -22,11 +22,40 @@ def allreduce_mean_(flat_grad: torch.Tensor, group=None) -> torch.Tensor:
     return flat_grad
 
 
+def allreduce_weighted_mean_(flat_grad: torch.Tensor, local_count, global_count, group=None) -> torch.Tensor:
+    """Gradient of the GLOBAL batch's mean loss from per-rank gradients of the LOCAL shards' mean losses:
+    sum_r (n_r / n) g_r -- one all-reduce; a rank with an empty shard passes zeros and n_r = 0."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if local_count is not None and global_count:
+            flat_grad.mul_(float(local_count) * dist.get_world_size(group) / float(global_count))
+        allreduce_mean_(flat_grad, group)
+    return flat_grad
+
+
 def shard_batch(n: int, rank: int, world: int):
     """Contiguous [start, stop) of a global batch of n images for `rank` (remainder to the first ranks)."""
     base, rem = divmod(n, world)
     start = rank * base + min(rank, rem)
     return start, start + base + (1 if rank < rem else 0)
+
+
+def global_batch_plan(n: int, batch: int, rank: int, world: int, shuffle_seed=None):
+    """The step schedule of one epoch, IDENTICAL in length on every rank: the dataset is cut into global batches of
+    `batch` samples (the reference's DataLoader batches, train_loras.py:237-243; shuffled with a seed every rank
+    shares) and each global batch into contiguous per-rank shards.  Returns [(local_indices, n_global), ...] with one
+    entry per optimizer step -- a rank whose shard of the last, ragged batch is empty still gets an entry (it
+    contributes a zero gradient and joins the all-reduce), so no rank can run a step the others do not."""
+    if shuffle_seed is None:
+        order = list(range(n))
+    else:
+        order = torch.randperm(n, generator=torch.Generator().manual_seed(int(shuffle_seed))).tolist()
+    plan = []
+    for s0 in range(0, n, batch):
+        gb = order[s0:s0 + batch]
+        lo, hi = shard_batch(len(gb), rank, world)
+        plan.append((gb[lo:hi], len(gb)))
+    return plan
 
 
 class Adam:
@@ -63,17 +92,25 @@ class Adam:
         raise TypeError("Adam needs model=<vitlora model or PeftModel>")
 
     @torch.no_grad()
-    def step(self):
+    def step(self, local_count: Optional[int] = None, global_count: Optional[int] = None):
+        """optimizer.step().  Data parallel: pass the number of samples behind this rank's (mean) gradient and
+        behind the whole global batch; the all-reduce then yields the gradient of the global-batch mean loss
+        also when shards differ in size or a shard is empty (p.grad None = zero contribution)."""
         p = self.params[0]
-        if p.grad is None:
-            return
-        g = p.grad.contiguous()
         import torch.distributed as dist
         use_dist = self.distributed if self.distributed is not None else (dist.is_available() and dist.is_initialized())
+        if p.grad is None:
+            if not use_dist:
+                return
+            g = torch.zeros_like(p.data)            # empty shard: still join the collective
+        else:
+            g = p.grad.contiguous()
         if use_dist:
-            allreduce_mean_(g, self.group)
+            g = g.clone() if p.grad is not None else g
+            allreduce_weighted_mean_(g, local_count, global_count, self.group)
         vit, eng = self._engine()
         self.t += 1
         lr = self.param_groups[0]["lr"]
         eng.adam_step(p.data, g, self.m1, self.m2, lr, self.betas[0], self.betas[1], self.eps, self.t)
-        vit.mark_dirty()          # bf16 operands are re-derived before the next forward
+        vit.mark_dirty()          # (vl_adam_step marked the handle itself: the fp16 operands are re-derived
+                                  #  by the library before the next forward / attack)

@@ -63,3 +63,39 @@ def random_batch(arch: ArchConfig, batch: int, seed: int = 0):
     x = torch.rand(batch, 3, arch.image_size, arch.image_size, generator=gx)
     y = torch.randint(0, arch.num_labels, (batch,), generator=gy)
     return x, y
+
+
+ARCHS = {
+    # name: (image_size, hidden, layers, heads, mlp)
+    "vit_b": (224, 768, 12, 12, 3072),       # google/vit-base-patch16-224 (Utils.py:84-90)
+    "vit_l": (224, 1024, 24, 16, 4096),      # ViT-L/16 (BASELINE config 5)
+    "tiny": (64, 128, 2, 2, 256),            # plumbing / test runs of the CLIs
+}
+
+
+def arch_by_name(name: str, num_labels: int) -> ArchConfig:
+    s, d, l, h, m = ARCHS[name]
+    return ArchConfig(image_size=s, hidden=d, layers=l, heads=h, mlp=m, num_labels=int(num_labels))
+
+
+def write_dataset_tree(root: str, classes, n_per_split=None, image_size: int = 64, seed: int = 0, source: str = "mapillary"):
+    """A dataset tree in the reference's on-disk layout (Utils.py:12-82, whitebox_attacks.py:118-133):
+    <root>/<split>/images/*.png + <root>/<split>/metadata.csv with columns image_path, unified_class, source.
+    Pixels are seeded noise with a class-dependent mean so that a head can learn something."""
+    import os
+
+    import pandas as pd
+    from PIL import Image
+    n_per_split = n_per_split or {"train": 48, "val": 16, "test": 16}
+    g = torch.Generator().manual_seed(seed)
+    for split, n in n_per_split.items():
+        d = os.path.join(root, split, "images")
+        os.makedirs(d, exist_ok=True)
+        rows = []
+        for i in range(n):
+            c = i % len(classes)
+            img = (torch.rand(image_size, image_size, 3, generator=g) * 0.6 + 0.4 * (c / max(1, len(classes) - 1)))
+            fn = f"{split}_{i:05d}.png"
+            Image.fromarray((img.clamp(0, 1) * 255).to(torch.uint8).numpy()).save(os.path.join(d, fn))
+            rows.append({"image_path": os.path.join(split, "images", fn), "unified_class": classes[c], "source": source})
+        pd.DataFrame(rows).to_csv(os.path.join(root, split, "metadata.csv"), index=False)

@@ -79,6 +79,9 @@ def main(argv=None):
     ap.add_argument("--test_mode", choices=["all", "base_only", "individual_only", "combinations_only"], default="all")
     ap.add_argument("--synthetic", type=int, default=0, metavar="N")
     ap.add_argument("--num_classes", type=int, default=21, help="only with --synthetic")
+    ap.add_argument("--arch", choices=["tiny", "vit_b", "vit_l"], default="vit_b")
+    ap.add_argument("--model_name", default="google_vit")
+    ap.add_argument("--source", default="mapillary")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args(argv)
     device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
@@ -89,7 +92,7 @@ def main(argv=None):
 
     if args.synthetic:
         num_classes = args.num_classes
-        arch = V.ArchConfig(num_labels=num_classes)
+        arch = syn.arch_by_name(args.arch, num_classes)
         base_sd = syn.random_state_dict(arch, seed=args.seed)
 
         def load_base():
@@ -105,7 +108,6 @@ def main(argv=None):
             for (i, t), (A, B) in syn.random_lora(arch, args.rank, ("q", "k", "v", "o", "fc2"), seed=args.seed + 100 + k).items():
                 eng.param(i, t, "A").copy_(A)
                 eng.param(i, t, "B").copy_(B)
-            pm._vit.mark_dirty()
             adapters[attack] = os.path.join(tmp.name, attack)
             pm.save_pretrained(adapters[attack])
         sets = {}
@@ -121,25 +123,27 @@ def main(argv=None):
         class_to_idx = iomod.read_class_mappings(os.path.join(os.path.dirname(args.model_path), "class_mappings.txt"))
         num_classes = len(class_to_idx)
 
+        arch = syn.arch_by_name(args.arch, num_classes)
+
         def load_base():
-            m = V.create_vit_model(num_classes)
+            m = V.create_vit_model(num_classes, arch=arch)
             m.load_state_dict(torch.load(args.model_path, map_location="cpu", weights_only=True))
             return m.to(device).eval()
 
         def loader(root, meta, sources=None):
-            ds = iomod.FolderDataset(root, meta, class_to_idx, sources=sources, normalise=(mean, std))
+            ds = iomod.FolderDataset(root, meta, class_to_idx, image_size=arch.image_size, sources=sources, normalise=(mean, std))
             return lambda: torch.utils.data.DataLoader(ds, batch_size=args.batch_size, shuffle=False,
                                                        num_workers=min(4, os.cpu_count() or 1))
 
-        sets = {"clean": loader(args.data_root, os.path.join(args.data_root, "test", "metadata.csv"), ["mapillary"])}
-        adv_base = os.path.join(args.adv_root, "google_vit", "mapillary", "test")
+        sets = {"clean": loader(args.data_root, os.path.join(args.data_root, "test", "metadata.csv"), [args.source])}
+        adv_base = os.path.join(args.adv_root, args.model_name, args.source, "test")
         for name in sorted(os.listdir(adv_base)) if os.path.isdir(adv_base) else []:
             meta = os.path.join(adv_base, name, "metadata.csv")
             if os.path.exists(meta):
                 sets[name] = loader(os.path.join(adv_base, name), meta)
         adapters = {}
         for attack in args.attacks:
-            p = os.path.join(args.lora_root, "google_vit", "mapillary", attack, f"rank{args.rank}_best_adapter")
+            p = os.path.join(args.lora_root, args.model_name, args.source, attack, f"rank{args.rank}_best_adapter")
             if os.path.exists(p):
                 adapters[attack] = p
             else:

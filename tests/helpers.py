@@ -52,3 +52,21 @@ def make_engine(cfg, w, lora=None, merged=False, dropout=0.0, precision="f16"):
         eng.commit()
     torch.cuda.synchronize()
     return eng
+
+
+def fmnist_labels(n=512):
+    """Real FashionMNIST test labels (idx1-ubyte: 8-byte header, then one byte per label) from the committed
+    copy of the head of the reference's fashion_data/FashionMNIST/raw/t10k-labels-idx1-ubyte."""
+    raw = open(os.path.join(ROOT, "tests", "golden", "fmnist_t10k_labels_512.bin"), "rb").read()
+    assert raw[:4] == b"\x00\x00\x08\x01"
+    return torch.tensor(list(raw[8:8 + n]), dtype=torch.int64)
+
+
+def fmnist_like_images(n, seed=0, size=224):
+    """BASELINE config 1 pixels: the FashionMNIST image files are not in the reference snapshot, so
+    seeded 28x28 uint8 noise -> bilinear resize to `size` -> grayscale replicated to 3 channels -> [0,1]
+    (the Resize / Grayscale(3) / ToTensor chain of train_bilora.ipynb:28-33)."""
+    g = torch.Generator().manual_seed(seed)
+    small = torch.randint(0, 256, (n, 1, 28, 28), generator=g).float() / 255.0
+    big = torch.nn.functional.interpolate(small, size=(size, size), mode="bilinear", align_corners=False)
+    return big.expand(n, 3, size, size).contiguous()

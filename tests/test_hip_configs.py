@@ -1,0 +1,371 @@
+"""GPU tests of the BASELINE.json configurations that round 1 never exercised, of the remaining golden vectors
+(G4 PGD trajectories driven by the reference's own batched_fgsm_attack, G5 LoRA around HF linears, G8
+Utils.save_images bytes) and of the C ABI's state handling (stale adapters, one PGD graph per run, refused inputs).
+
+  config 1   ViT-B/16 + LoRA r=4, FGSM eps=8/255, 512 FashionMNIST-like images, batch 32 (real labels from the
+             reference's t10k label file, synthesised pixels: the image files are not in the reference snapshot)
+  config 3   one data-parallel rank's share of the adversarial fine-tune: PGD-7 on 64 images, then the LoRA train
+             step on the adversarial batch (train_loras.py:303-315 with the attack generated on the fly)
+"""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import O, PKG, fmnist_labels, fmnist_like_images, make_case, make_engine, pkg, rel_l2
+from test_oracle_golden import GOLD, load_case
+
+pytestmark = pytest.mark.gpu
+
+PRECS = ["f16", "f32"]
+TOL_ACT = {"f16": 4e-3, "f32": 1e-4}
+TOL_GRAD = {"f16": 6e-3, "f32": 1e-4}
+EPS, ALPHA = 8 / 255, 2 / 255
+TARGETS = ("q", "k", "v", "o", "fc2")        # ["query","key","value","output.dense"], train_loras.py:81
+
+
+def flat_slices(eng, cfg, lora):
+    base = eng.flat.data_ptr()
+    out = {}
+    for i in range(cfg.layers):
+        for t in lora.targets:
+            for which in ("A", "B"):
+                v = eng.param(i, t, which)
+                off = (v.data_ptr() - base) // 4
+                out[(which, i, t)] = (off, v.numel(), tuple(v.shape))
+    for which in ("weight", "bias"):
+        v = eng.param(-1, "", which)
+        out[("cls", which)] = ((v.data_ptr() - base) // 4, v.numel(), tuple(v.shape))
+    eng.commit()          # param() handed out writable views: settle the dirty flag
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# golden vectors on the GPU
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("name", ["tiny17", "vitb"])
+def test_golden_pgd_trajectories(name, prec):
+    """G4: vl_pgd_attack against trajectories whose ascent step is the imported reference function on the HF model."""
+    cfg, w, x, y, _ = load_case(name)
+    z = np.load(os.path.join(GOLD, f"pgd_{name}.npz"))
+    eng = make_engine(cfg, w, None, precision=prec)
+    eps, alpha = float(z["eps"]), float(z["alpha"])
+    for k in [int(v) for v in z["steps"]]:
+        adv = eng.pgd_attack(x.cuda(), y.cuda(), eps, alpha, k, random_start=False).cpu()
+        ref = x + torch.from_numpy(z[f"delta_x0_{k}"])
+        same = ((adv - ref).abs() < 1e-6).float().mean().item()
+        # every iteration re-decides sign(g) for all pixels: a flipped near-zero gradient entry moves that pixel by
+        # 2 alpha and later iterations see the difference, so agreement decays slowly with k
+        floor = {"f16": {1: 0.998, 3: 0.99, 7: 0.97}, "f32": {1: 0.9999, 3: 0.9995, 7: 0.999}}[prec][k]
+        assert same > floor, (name, k, same)
+        assert (adv - x).abs().max().item() <= eps + 1e-6
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("name,r", [("tiny17", 4), ("tiny17", 16), ("tiny197", 8), ("vitb", 4), ("vitb", 8), ("vitb", 16)])
+def test_golden_lora_logits_and_gradients(name, r, prec):
+    """G5: logits, d(A), d(B), d(classifier) against plain-torch low-rank branches around the HF model's linears --
+    the ViT-B-size LoRA gradient check (12 layers, r in {4, 8, 16})."""
+    cfg, w, x, y, _ = load_case(name)
+    z = np.load(os.path.join(GOLD, f"lora_{name}.npz"))
+    seed = int(np.load(os.path.join(GOLD, f"fgsm_{name}.npz"))["meta"][8])
+    lora = O.init_lora(cfg, r=r, targets=TARGETS, seed=seed + 100 + r, b_std=0.02 if name == "vitb" else 0.05)
+    eng = make_engine(cfg, w, lora, precision=prec)
+    sl = flat_slices(eng, cfg, lora)
+    logits = eng.forward(x.cuda(), normalise=True, train=True).cpu()
+    loss = eng.loss_ce(y.cuda()).item()
+    _, gp = eng.backward(False, True)
+    gp = gp.cpu()
+    assert rel_l2(logits, torch.from_numpy(z[f"r{r}_logits"])) < TOL_ACT[prec]
+    assert abs(loss - float(z[f"r{r}_loss"])) < TOL_ACT[prec] * float(z[f"r{r}_loss"])
+
+    def got(key):
+        off, n, shape = sl[key]
+        return gp[off:off + n].view(shape)
+
+    assert rel_l2(got(("cls", "weight")), torch.from_numpy(z[f"r{r}_dcls_w"])) < TOL_GRAD[prec]
+    assert rel_l2(got(("cls", "bias")), torch.from_numpy(z[f"r{r}_dcls_b"])) < TOL_GRAD[prec]
+    checked = 0
+    for key in z.files:
+        if key.startswith(f"r{r}_dA_") or key.startswith(f"r{r}_dB_"):
+            _, which, i, t = key.split("_", 3)
+            e = rel_l2(got((which[1], int(i), t)), torch.from_numpy(z[key]))
+            assert e < TOL_GRAD[prec], (key, e)
+            checked += 1
+    assert checked >= 6
+    norms = z[f"r{r}_grad_norms"]                      # every (layer, target): gradient norms
+    for (i, t), (na, nb) in zip(sorted(lora.ab.keys()), norms):
+        assert abs(float(got(("A", i, t)).double().norm()) - na) < TOL_GRAD[prec] * na + 1e-12, (i, t)
+        assert abs(float(got(("B", i, t)).double().norm()) - nb) < TOL_GRAD[prec] * nb + 1e-12, (i, t)
+
+
+def test_golden_save_images_bytes():
+    """G8: vl_quantize_u8 == the bytes the reference's Utils.save_images wrote."""
+    z = np.load(os.path.join(GOLD, "save_images.npz"))
+    cfg, w, _, _, _ = make_case(batch=1, r=0)
+    eng = make_engine(cfg, w)
+    assert torch.equal(eng.quantize_u8(torch.from_numpy(z["images"]).cuda()).cpu(), torch.from_numpy(z["bytes_hwc"]))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# BASELINE config 1
+# ------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def config1():
+    cfg = O.OracleConfig(num_labels=10)
+    w = O.init_weights(cfg, seed=21)
+    lora = O.init_lora(cfg, r=4, targets=TARGETS, seed=22, b_std=0.02)
+    return cfg, w, lora, fmnist_like_images(512, seed=23), fmnist_labels(512)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_config1_fgsm_first_batch_against_oracle(config1, prec):
+    cfg, w, lora, x, y = config1
+    P = pkg()
+    eng = make_engine(cfg, w, lora, precision=prec)
+    xb, yb = x[:32], y[:32]
+    logits = eng.forward(xb.cuda(), normalise=True).cpu()
+    torch.set_num_threads(16)
+    l_ref, g_ref, lg_ref = O.loss_and_input_grad(w, cfg, xb, yb, lora)
+    assert rel_l2(logits, lg_ref) < TOL_ACT[prec]
+    eng.loss_ce(yb.cuda())
+    gx, _ = eng.backward(True, False, tuple(xb.shape))
+    assert rel_l2(gx.cpu(), g_ref) < TOL_GRAD[prec]
+    # FGSM through the reference's signature
+    model = P.create_vit_model(cfg.num_labels, precision=prec)
+    model.load_state_dict(w)
+    pm = P.setup_peft_lora(model, rank=4, alpha=16, dropout=0.0)
+    for (i, t), (A, B) in lora.ab.items():
+        pm._vit._engine().param(i, t, "A").copy_(A)
+        pm._vit._engine().param(i, t, "B").copy_(B)
+    mean, std = P.get_normalization("google_vit")
+    mt, st = torch.tensor(mean).view(1, 3, 1, 1).cuda(), torch.tensor(std).view(1, 3, 1, 1).cuda()
+    adv = P.batched_fgsm_attack(pm.eval(), xb.cuda(), yb.cuda(), EPS, mt, st).cpu()
+    ref = torch.clamp(xb + EPS * torch.sign(g_ref), 0, 1)
+    same = ((adv - ref).abs() < 1e-6).float().mean().item()
+    assert same > (0.998 if prec == "f16" else 0.9999), same
+
+
+def test_config1_all_512_images_properties(config1):
+    cfg, w, lora, x, y = config1
+    eng = make_engine(cfg, w, lora)
+    advs = []
+    for b in range(16):
+        xb, yb = x[32 * b:32 * b + 32].cuda(), y[32 * b:32 * b + 32].cuda()
+        eng.forward(xb, normalise=True)
+        eng.loss_ce(yb)
+        gx, _ = eng.backward(True, False, tuple(xb.shape))
+        adv = xb.clone()
+        eng.pgd_step(adv, xb, gx, EPS, EPS)
+        advs.append(adv)
+    adv = torch.cat(advs)
+    xg = x.cuda()
+    assert torch.isfinite(adv).all() and adv.min().item() >= 0 and adv.max().item() <= 1
+    assert (adv - xg).abs().max().item() <= EPS + 1e-6
+    assert ((adv - xg).abs() > 1e-7).float().mean().item() > 0.95          # FGSM moves (almost) every pixel by eps
+    # an image's adversarial example does not depend on which batch it was attacked in (per-image gradient scale,
+    # 1/B of the mean loss vanishes under sign): re-attack a batch assembled from eight different batches
+    idx = torch.arange(5, 512, 16)[:32]
+    xb, yb = xg[idx].contiguous(), y[idx].cuda()
+    eng.forward(xb, normalise=True)
+    eng.loss_ce(yb)
+    gx, _ = eng.backward(True, False, tuple(xb.shape))
+    again = xb.clone()
+    eng.pgd_step(again, xb, gx, EPS, EPS)
+    assert torch.equal(again, adv[idx.cuda()])
+
+
+# ------------------------------------------------------------------------------------------------------------
+# BASELINE config 3: PGD-7 inside the train step
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", PRECS)
+def test_config3_composition_against_oracle_small(prec):
+    """pgd -> lora_train_grads composed on the device (no PNG round trip) against the oracle's composition."""
+    cfg, w, lora, x, y = make_case(batch=6, layers=2)
+    eng = make_engine(cfg, w, lora, precision=prec)
+    sl = flat_slices(eng, cfg, lora)
+    adv = eng.pgd_attack(x.cuda(), y.cuda(), EPS, ALPHA, 7, random_start=False)
+    ref_adv = O.pgd(w, cfg, x, y, EPS, ALPHA, 7, lora)
+    assert ((adv.cpu() - ref_adv).abs() < 1e-6).float().mean().item() > (0.97 if prec == "f16" else 0.999)
+    # second stage on the adversarial batch the device produced (train_loras.py:310-314; images normalised first)
+    xn = O.normalise(adv.cpu())
+    logits = eng.forward(adv, normalise=True, train=True).cpu()
+    loss = eng.loss_ce(y.cuda()).item()
+    _, gp = eng.backward(False, True)
+    gp = gp.cpu()
+    l_ref, lg_ref, grads = O.lora_train_grads(w, cfg, xn, y, lora)
+    assert rel_l2(logits, lg_ref) < TOL_ACT[prec] and abs(loss - l_ref.item()) < TOL_ACT[prec] * l_ref.item()
+    for key, (off, n, shape) in sl.items():
+        k2 = key if key[0] == "cls" else key
+        assert rel_l2(gp[off:off + n].view(shape), grads[k2]) < TOL_GRAD[prec], key
+
+
+def test_config3_vitb_64_images_pgd7_then_train_step():
+    """One rank's share of config 3 at full size (ViT-B/16, r = 8, 64 images, PGD-7, LoRA dropout 0): properties the
+    domain offers -- eps-ball, finite gradients, the data-parallel identity mean(shard gradients) == full-batch
+    gradient (the ONE all-reduce), and a falling loss over Adam steps on the same batch."""
+    P = pkg()
+    syn = importlib.import_module(PKG + ".synthetic")
+    arch = P.ArchConfig(num_labels=21)
+    eng = P.Engine(arch, P.LoraSpec(r=8, alpha=16.0, dropout=0.0, targets=TARGETS))
+    eng.load_state_dict(syn.random_state_dict(arch, seed=0))
+    for (i, t), (A, B) in syn.random_lora(arch, 8, TARGETS, seed=1).items():
+        eng.param(i, t, "A").copy_(A)
+        eng.param(i, t, "B").copy_(B)
+    x, y = syn.random_batch(arch, 64, seed=300)
+    x, y = x.cuda(), y.cuda()
+    eng.plan(64, train=True)
+    adv = eng.pgd_attack(x, y, EPS, ALPHA, 7, random_start=True, seed=5).clone()
+    assert (adv - x).abs().max().item() <= EPS + 1e-6 and adv.min().item() >= 0 and adv.max().item() <= 1
+
+    def grads(lo, hi):
+        eng.forward(adv[lo:hi].contiguous(), normalise=True, train=True)
+        loss = eng.loss_ce(y[lo:hi].contiguous()).item()
+        _, g = eng.backward(False, True)
+        return loss, g.clone()
+
+    l_full, g_full = grads(0, 64)
+    l_a, g_a = grads(0, 32)
+    l_b, g_b = grads(32, 64)
+    assert torch.isfinite(g_full).all() and g_full.abs().max().item() > 0
+    assert abs(l_full - 0.5 * (l_a + l_b)) < 1e-3 * l_full
+    assert rel_l2(0.5 * (g_a + g_b), g_full) < 2e-3            # two fp16 passes over different batch tilings
+    # three optimizer steps on the same adversarial batch lower its loss (train_loras.py:308-315)
+    m1, m2 = torch.zeros_like(eng.flat), torch.zeros_like(eng.flat)
+    losses = []
+    for t in range(1, 4):
+        loss, g = grads(0, 64)
+        losses.append(loss)
+        eng.adam_step(eng.flat, g, m1, m2, 1e-3, 0.9, 0.999, 1e-8, t)
+    assert losses[2] < losses[0], losses
+
+
+# ------------------------------------------------------------------------------------------------------------
+# state handling below the CLIs
+# ------------------------------------------------------------------------------------------------------------
+def test_attack_after_train_step_uses_the_updated_adapters():
+    """PGD-k, one Adam step on the flat parameters, PGD-k again -- WITHOUT any explicit commit: the second attack
+    must be the attack on the UPDATED model (train_loras.py --pgd-inner-steps)."""
+    cfg, w, lora, x, y = make_case(batch=4)
+    eng = make_engine(cfg, w, lora)
+    sl = flat_slices(eng, cfg, lora)
+    steps = 3
+    adv0 = eng.pgd_attack(x.cuda(), y.cuda(), EPS, ALPHA, steps, random_start=False).clone()
+    eng.forward(O.normalise(x).cuda(), normalise=False, train=True)
+    eng.loss_ce(y.cuda())
+    _, g = eng.backward(False, True)
+    m1, m2 = torch.zeros_like(eng.flat), torch.zeros_like(eng.flat)
+    lr = 5e-2                                           # a large step so that the two models attack differently
+    eng.adam_step(eng.flat, g, m1, m2, lr, 0.9, 0.999, 1e-8, 1)
+    assert eng.counter("dirty") == 1
+    commits = eng.counter("commits")
+    adv1 = eng.pgd_attack(x.cuda(), y.cuda(), EPS, ALPHA, steps, random_start=False).cpu()
+    assert eng.counter("commits") == commits + 1 and eng.counter("dirty") == 0
+    # oracle with the same update applied
+    _, _, grads = O.lora_train_grads(w, cfg, O.normalise(x), y, lora)
+    w2 = dict(w)
+    l2 = O.OracleLora(r=lora.r, alpha=lora.alpha, targets=lora.targets)
+    for (i, t), (A, B) in lora.ab.items():
+        A2, _, _ = O.adam_step(A, grads[("A", i, t)], torch.zeros_like(A), torch.zeros_like(A), 1, lr=lr)
+        B2, _, _ = O.adam_step(B, grads[("B", i, t)], torch.zeros_like(B), torch.zeros_like(B), 1, lr=lr)
+        l2.ab[(i, t)] = (A2, B2)
+    for nm in ("weight", "bias"):
+        p = w["classifier." + nm]
+        w2["classifier." + nm], _, _ = O.adam_step(p, grads[("cls", nm)], torch.zeros_like(p), torch.zeros_like(p), 1, lr=lr)
+    ref_new = O.pgd(w2, cfg, x, y, EPS, ALPHA, steps, l2)
+    ref_old = O.pgd(w, cfg, x, y, EPS, ALPHA, steps, lora)
+    same_new = ((adv1 - ref_new).abs() < 1e-6).float().mean().item()
+    same_old = ((adv1 - ref_old).abs() < 1e-6).float().mean().item()
+    assert same_new > 0.97 and same_old < same_new - 0.02, (same_new, same_old)
+    assert ((adv0.cpu() - ref_old).abs() < 1e-6).float().mean().item() > 0.97
+
+
+def test_attack_through_a_loaded_adapter_differs_from_the_base_model(tmp_path):
+    """whitebox_attacks.py --lora_dir X --attacks pgd: PeftModel.from_pretrained then the attack, no commit call."""
+    P = pkg()
+    cfg, w, lora, x, y = make_case(batch=4, b_std=0.2)
+    arch = P.ArchConfig(image_size=cfg.image_size, hidden=cfg.hidden, layers=cfg.layers, heads=cfg.heads, mlp=cfg.mlp,
+                        num_labels=cfg.num_labels)
+    base = P.create_vit_model(cfg.num_labels, arch=arch)
+    base.load_state_dict(w)
+    pm = P.setup_peft_lora(base, rank=lora.r, alpha=lora.alpha, dropout=0.0)
+    for (i, t), (A, B) in lora.ab.items():
+        pm._vit._engine().param(i, t, "A").copy_(A)
+        pm._vit._engine().param(i, t, "B").copy_(B)
+    d = str(tmp_path / "adapter")
+    pm.save_pretrained(d)
+    loaded = P.PeftModel.from_pretrained(base, d).eval()
+    eng = loaded._vit._engine()
+    adv = eng.pgd_attack(x.cuda(), y.cuda(), EPS, ALPHA, 3, random_start=False).cpu()
+    ref_lora = O.pgd(w, cfg, x, y, EPS, ALPHA, 3, lora)
+    ref_base = O.pgd(w, cfg, x, y, EPS, ALPHA, 3, None)
+    s_l = ((adv - ref_lora).abs() < 1e-6).float().mean().item()
+    s_b = ((adv - ref_base).abs() < 1e-6).float().mean().item()
+    assert s_l > 0.97 and s_b < s_l - 0.05, (s_l, s_b)
+
+
+def test_one_pgd_graph_serves_every_batch_of_a_run():
+    """Fresh image / label / output tensors per batch (what the CLIs pass) must not re-capture the iteration graph."""
+    cfg, w, lora, x, y = make_case(batch=8)
+    eng = make_engine(cfg, w, lora)
+    c0 = eng.counter("graph_captures")
+    outs = []
+    for b in range(3):
+        xb, yb = x.clone().cuda(), y.clone().cuda()       # new allocations every time
+        outs.append(eng.pgd_attack(xb, yb, EPS, ALPHA, 4, random_start=False))
+    assert eng.counter("graph_captures") == c0 + 1
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    eng.pgd_attack(x[:5].cuda(), y[:5].cuda(), EPS, ALPHA, 4, random_start=False)      # ragged last batch: one more
+    eng.pgd_attack(x.clone().cuda(), y.clone().cuda(), EPS, ALPHA, 4, random_start=False)
+    assert eng.counter("graph_captures") == c0 + 2
+    # the output may alias the input now that the attack runs on the staging buffers
+    xin = x.clone().cuda()
+    out = eng.pgd_attack(xin, y.cuda(), EPS, ALPHA, 4, random_start=False, out=xin)
+    assert torch.equal(out, outs[0])
+
+
+def test_cli_whitebox_synthetic_captures_one_graph(tmp_path, monkeypatch):
+    """whitebox_attacks.py --synthetic 96 --batch_size 32 (three batches): exactly one capture."""
+    import whitebox_attacks as cli
+    P = pkg()
+    seen = []
+    orig = P.Engine.pgd_attack
+
+    def spy(self, *a, **k):
+        r = orig(self, *a, **k)
+        seen.append(self.counter("graph_captures"))
+        return r
+
+    monkeypatch.setattr(P.Engine, "pgd_attack", spy)
+    cli.main(["--models", "google_vit", "--sources", "synthetic", "--output_dir", str(tmp_path), "--synthetic", "96",
+              "--batch_size", "32", "--attacks", "pgd", "--pgd_iters", "2", "--splits", "test", "--tiny"])
+    assert len(seen) == 3 and seen == [1, 1, 1], seen
+    pngs = os.listdir(os.path.join(str(tmp_path), "google_vit", "synthetic", "test", "pgd", "images"))
+    assert len(pngs) == 96
+
+
+def test_refused_inputs_fail_loudly():
+    P = pkg()
+    # more tokens than the attention kernels hold (T <= 224): refused at vl_create, not silently wrong
+    with pytest.raises(P.VitLoraError):
+        P.Engine(P.ArchConfig(image_size=256, patch_size=16, hidden=128, heads=2, mlp=256, layers=1))
+    with pytest.raises(P.VitLoraError):
+        P.Engine(P.ArchConfig(hidden=96, heads=2, mlp=256, layers=1))                  # head_dim != 64
+    cfg, w, lora, x, y = make_case(batch=3, r=0)
+    eng = make_engine(cfg, w)
+    eng.forward(x.cuda(), normalise=True)
+    bad = y.clone()
+    bad[1] = cfg.num_labels                         # out of range
+    loss = eng.loss_ce(bad.cuda())
+    torch.cuda.synchronize()
+    assert not torch.isfinite(loss).item()          # NaN, never a wild read
+    with pytest.raises(P.VitLoraError, match="label"):
+        eng.forward(x.cuda(), normalise=True)       # the next call reports it
+    # and the engine recovers
+    logits = eng.forward(x.cuda(), normalise=True).cpu()
+    assert rel_l2(logits, O.vit_forward(w, cfg, O.normalise(x), None)) < TOL_ACT["f16"]
+    with pytest.raises(P.VitLoraError):             # backward before any loss
+        eng.backward(True, False, tuple(x.shape))

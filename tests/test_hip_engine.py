@@ -1,8 +1,13 @@
-"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded
-inputs.  Two oracles modes are used:
-  * sim16 = the oracle with bf16 round trips where the kernels store bf16 -> tight
-    tolerances that check the kernels' logic (indexing, masking, softmax, LoRA fusion);
-  * fp32     = the reference arithmetic -> the north-star bf16 tolerance (1e-2 relative).
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs, in both
+precisions of vl_config:
+
+  * "f32"  every operand fp32 (exact-f32 MFMA): held to TOL["f32"] = 1e-4 -- north_star allows 1e-3;
+  * "f16"  fp16 operands, fp32 accumulation: held to 4e-3 on logits / activations and 6e-3 on gradients --
+           north_star allows 1e-2 for the 16-bit path.  (bf16 operands sat AT 1e-2 on the ViT-B input gradient:
+           tools/error_budget.py; that is why the 16-bit type is fp16.)
+
+Every comparison is against the fp32 oracle (the reference arithmetic); the oracle's sim16 mode (fp16 round trips
+where the kernels store 16-bit values) is used additionally where a tighter bound on kernel LOGIC is wanted.
 """
 import pytest
 import torch
@@ -11,9 +16,10 @@ from helpers import O, make_case, make_engine, rel_l2
 
 pytestmark = pytest.mark.gpu
 
-TOL_SIM_LOGITS = 7e-3
-TOL_SIM = 4e-3      # HIP bf16 path vs bf16-simulating oracle (accumulation order only)
-TOL_FP32 = 1e-2     # north_star: 1e-2 relative for the bf16 path vs the fp32 reference path
+PRECS = ["f16", "f32"]
+TOL_ACT = {"f16": 4e-3, "f32": 1e-4}       # logits, residual stream, qkv, ctx, loss
+TOL_GRAD = {"f16": 6e-3, "f32": 1e-4}      # dLoss/dx, LoRA A/B gradients, classifier gradients
+TOL_SIM = 2e-3                             # f16 path vs the fp16-simulating oracle (accumulation order only)
 
 
 def _trace(cfg, w, lora, x_norm, sim):
@@ -23,15 +29,16 @@ def _trace(cfg, w, lora, x_norm, sim):
     return tr
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("image_size,batch", [(64, 4), (224, 3)])
 @pytest.mark.parametrize("with_lora", [False, True])
-def test_forward_stagewise(image_size, batch, with_lora):
+def test_forward_stagewise(image_size, batch, with_lora, prec):
     cfg, w, lora, x, y = make_case(image_size=image_size, batch=batch, r=8 if with_lora else 0)
-    eng = make_engine(cfg, w, lora)
+    eng = make_engine(cfg, w, lora, precision=prec)
     xn = O.normalise(x)
     logits = eng.forward(xn.cuda(), normalise=False)
     torch.cuda.synchronize()
-    tr = _trace(cfg, w, lora, xn, sim=True)
+    tr = _trace(cfg, w, lora, xn, sim=False)
     B, T, D = batch, cfg.tokens, cfg.hidden
     report = []
     for i in range(2 * cfg.layers + 1):
@@ -43,75 +50,71 @@ def test_forward_stagewise(image_size, batch, with_lora):
         got = eng.debug_tensor("ctx", l).float().cpu().view(B, T, D)
         report.append((f"ctx{l}", rel_l2(got, tr[f"ctx{l}"])))
     report.append(("logits", rel_l2(logits.cpu(), tr["logits"])))
-    # logits: a small-magnitude difference of large activations after the last of 2L bf16 residual deltas;
-    # rounding-boundary flips between the two accumulation orders show up there first
-    bad = [(n, e) for n, e in report if not (e < (TOL_SIM_LOGITS if n == "logits" else TOL_SIM))]
+    bad = [(n, e) for n, e in report if not (e < TOL_ACT[prec])]
     assert not bad, f"stages off: {bad}\nall: {report}"
-    # and against the fp32 reference arithmetic
-    ref = O.vit_forward(w, cfg, xn, lora)
-    assert rel_l2(logits.cpu(), ref) < TOL_FP32
+    if prec == "f16":       # kernel logic: against the oracle that rounds where the kernels round
+        sim = _trace(cfg, w, lora, xn, sim=True)
+        assert rel_l2(logits.cpu(), sim["logits"]) < TOL_SIM
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("image_size,batch", [(64, 4), (224, 3)])
 @pytest.mark.parametrize("with_lora", [False, True])
-def test_loss_and_input_grad(image_size, batch, with_lora):
+def test_loss_and_input_grad(image_size, batch, with_lora, prec):
     cfg, w, lora, x, y = make_case(image_size=image_size, batch=batch, r=8 if with_lora else 0)
-    eng = make_engine(cfg, w, lora)
+    eng = make_engine(cfg, w, lora, precision=prec)
     logits = eng.forward(x.cuda(), normalise=True)
     loss = eng.loss_ce(y.cuda())
     gx, _ = eng.backward(True, False, tuple(x.shape))
     torch.cuda.synchronize()
-    l_sim, g_sim, _ = O.loss_and_input_grad(w, cfg, x, y, lora, sim16=True)
     l_ref, g_ref, lg_ref = O.loss_and_input_grad(w, cfg, x, y, lora)
-    assert abs(loss.item() - l_sim.item()) < 2e-3 * max(1.0, abs(l_sim.item()))
-    e_sim, e_ref = rel_l2(gx.cpu(), g_sim), rel_l2(gx.cpu(), g_ref)
-    assert e_sim < 1e-2, (e_sim, e_ref)
-    assert e_ref < 2e-2, (e_sim, e_ref)   # input gradient through 2x bf16 chains; logits/loss hold 1e-2
-    assert rel_l2(logits.cpu(), lg_ref) < TOL_FP32
-    # sign agreement where the gradient is not in the rounding noise
+    assert abs(loss.item() - l_ref.item()) < TOL_ACT[prec] * max(1.0, abs(l_ref.item()))
+    assert rel_l2(logits.cpu(), lg_ref) < TOL_ACT[prec]
+    assert rel_l2(gx.cpu(), g_ref) < TOL_GRAD[prec], rel_l2(gx.cpu(), g_ref)
+    # FGSM / PGD consume sign(g): agreement over ALL pixels, and where the gradient is not in the rounding noise
+    agree_all = (torch.sign(gx.cpu()) == torch.sign(g_ref)).float().mean().item()
     big = g_ref.abs() > 0.05 * g_ref.abs().mean()
     agree = (torch.sign(gx.cpu())[big] == torch.sign(g_ref)[big]).float().mean().item()
-    assert agree > 0.97, agree
+    assert agree > 0.9995 and agree_all > (0.998 if prec == "f16" else 0.99995), (agree, agree_all)
 
 
 @pytest.mark.parametrize("r,targets", [(4, ("q", "v")), (8, ("q",)), (16, ("q", "v")), (16, ("o", "fc2")), (32, ("q", "o", "fc2")), (8, ("fc1", "fc2"))])
-def test_lora_down_fusion_variants(r, targets):
+@pytest.mark.parametrize("prec", PRECS)
+def test_lora_down_fusion_variants(r, targets, prec):
     """The LoRA down-projections are computed by different kernels depending on r * modules (fused into the
     LayerNorm forward / backward rows for <= 8 / <= 16 columns, skinny GEMM otherwise): every route must agree
     with the oracle on logits and on the input gradient."""
     cfg, w, lora, x, y = make_case(image_size=64, batch=4, r=r, targets=targets)
-    eng = make_engine(cfg, w, lora)
+    eng = make_engine(cfg, w, lora, precision=prec)
     logits = eng.forward(x.cuda(), normalise=True)
     eng.loss_ce(y.cuda())
     gx, _ = eng.backward(True, False, tuple(x.shape))
     torch.cuda.synchronize()
-    _, g_sim, lg_sim = O.loss_and_input_grad(w, cfg, x, y, lora, sim16=True)
     _, g_ref, lg_ref = O.loss_and_input_grad(w, cfg, x, y, lora)
-    assert rel_l2(logits.cpu(), lg_sim) < TOL_SIM_LOGITS
-    assert rel_l2(logits.cpu(), lg_ref) < TOL_FP32
-    assert rel_l2(gx.cpu(), g_sim) < 1e-2
-    assert rel_l2(gx.cpu(), g_ref) < 2e-2
+    assert rel_l2(logits.cpu(), lg_ref) < TOL_ACT[prec]
+    assert rel_l2(gx.cpu(), g_ref) < TOL_GRAD[prec]
     # the LoRA branch must matter in this case (otherwise the test proves nothing)
     _, g_nolora, _ = O.loss_and_input_grad(w, cfg, x, y, None)
     assert rel_l2(g_ref, g_nolora) > 5e-2
 
 
 @pytest.mark.parametrize("hidden,heads,mlp,layers,r", [(256, 4, 1024, 2, 8), (1024, 16, 4096, 1, 16)])
-def test_other_widths_run_the_256_row_gemm(hidden, heads, mlp, layers, r):
+@pytest.mark.parametrize("prec", PRECS)
+def test_other_widths_run_the_256_row_gemm(hidden, heads, mlp, layers, r, prec):
     """Widths other than ViT-B's: hidden 256 (K only 4-5 tiles deep: the shortest pipeline the 256-row GEMM accepts)
     and the ViT-L/16 width (hidden 1024, 16 heads, mlp 4096, LoRA r = 16: BASELINE config 5's model family)."""
     cfg, w, lora, x, y = make_case(image_size=224, hidden=hidden, heads=heads, mlp=mlp, layers=layers, batch=3, r=r,
                                    std=0.03 if hidden == 1024 else 0.05)
-    eng = make_engine(cfg, w, lora)
+    eng = make_engine(cfg, w, lora, precision=prec)
     logits = eng.forward(x.cuda(), normalise=True)
     eng.loss_ce(y.cuda())
     gx, _ = eng.backward(True, False, tuple(x.shape))
     torch.cuda.synchronize()
     _, g_ref, lg_ref = O.loss_and_input_grad(w, cfg, x, y, lora)
-    assert rel_l2(logits.cpu(), lg_ref) < TOL_FP32
-    assert rel_l2(gx.cpu(), g_ref) < 2e-2
+    assert rel_l2(logits.cpu(), lg_ref) < TOL_ACT[prec]
+    assert rel_l2(gx.cpu(), g_ref) < TOL_GRAD[prec]
     big = g_ref.abs() > 0.05 * g_ref.abs().mean()
-    assert (torch.sign(gx.cpu())[big] == torch.sign(g_ref)[big]).float().mean().item() > 0.97
+    assert (torch.sign(gx.cpu())[big] == torch.sign(g_ref)[big]).float().mean().item() > 0.9995
 
 
 def test_ragged_batches_replanning_and_empty_input():
@@ -122,7 +125,7 @@ def test_ragged_batches_replanning_and_empty_input():
     ref = O.vit_forward(w, cfg, O.normalise(x), lora)
     for b in (1, 5, 7, 2):                       # grows the plan at 5 and 7, reuses it at 2
         got = eng.forward(x[:b].cuda(), normalise=True).cpu()
-        assert rel_l2(got, ref[:b]) < TOL_FP32, b
+        assert rel_l2(got, ref[:b]) < TOL_ACT["f16"], b
     # attack on a ragged batch stays in the eps-ball and is the slice of the larger batch
     adv7 = eng.pgd_attack(x.cuda(), y.cuda(), 8 / 255, 2 / 255, 3, random_start=False).clone()
     adv3 = eng.pgd_attack(x[2:5].cuda(), y[2:5].cuda(), 8 / 255, 2 / 255, 3, random_start=False)
@@ -133,7 +136,7 @@ def test_ragged_batches_replanning_and_empty_input():
     with pytest.raises(ValueError):
         eng.forward(torch.zeros(2, 3, 32, 32).cuda(), normalise=True)
     # the engine still works after the refused calls
-    assert rel_l2(eng.forward(x[:3].cuda(), normalise=True).cpu(), ref[:3]) < TOL_FP32
+    assert rel_l2(eng.forward(x[:3].cuda(), normalise=True).cpu(), ref[:3]) < TOL_ACT["f16"]
 
 
 def test_unnormalised_forward_equals_normalised_input():
@@ -144,13 +147,14 @@ def test_unnormalised_forward_equals_normalised_input():
     assert rel_l2(a.cpu(), b.cpu()) < 2e-3
 
 
-def test_merged_matches_fused():
+@pytest.mark.parametrize("prec", PRECS)
+def test_merged_matches_fused(prec):
     cfg, w, lora, x, y = make_case(batch=3)
-    fused = make_engine(cfg, w, lora).forward(x.cuda(), normalise=True).cpu()
-    merged = make_engine(cfg, w, lora, merged=True).forward(x.cuda(), normalise=True).cpu()
+    fused = make_engine(cfg, w, lora, precision=prec).forward(x.cuda(), normalise=True).cpu()
+    merged = make_engine(cfg, w, lora, merged=True, precision=prec).forward(x.cuda(), normalise=True).cpu()
     ref = O.vit_forward(w, cfg, O.normalise(x), lora)
-    assert rel_l2(merged, ref) < TOL_FP32
-    assert rel_l2(fused, merged) < TOL_FP32
+    assert rel_l2(merged, ref) < TOL_ACT[prec]
+    assert rel_l2(fused, merged) < TOL_ACT[prec]
 
 
 def test_pgd_step_kernel_bit_exact():
@@ -175,17 +179,18 @@ def test_pgd_step_kernel_bit_exact():
     assert torch.equal(a.cpu(), torch.clamp(x0 + eps * torch.sign(g), 0, 1))
 
 
-def test_pgd_attack_matches_oracle_trajectory():
+@pytest.mark.parametrize("prec", PRECS)
+def test_pgd_attack_matches_oracle_trajectory(prec):
     cfg, w, lora, x, y = make_case(batch=4)
-    eng = make_engine(cfg, w, lora)
+    eng = make_engine(cfg, w, lora, precision=prec)
     eps, alpha, steps = 8 / 255, 2 / 255, 5
     adv = eng.pgd_attack(x.cuda(), y.cuda(), eps, alpha, steps, random_start=False).cpu()
     ref = O.pgd(w, cfg, x, y, eps, alpha, steps, lora)
     assert (adv - x).abs().max().item() <= eps + 1e-6
     assert adv.min().item() >= 0 and adv.max().item() <= 1
-    # sign() is discontinuous: compare the decisions, not the floats
-    agree = (torch.sign(adv - x) == torch.sign(ref - x)).float().mean().item()
-    assert agree > 0.90, agree
+    # sign() is discontinuous and PGD feeds each iterate back: compare pixels, allowing the few that flipped
+    same = ((adv - ref).abs() < 1e-6).float().mean().item()
+    assert same > (0.985 if prec == "f16" else 0.9995), same
     # the attack must be as strong as the oracle's
     l_hip = O.loss_and_input_grad(w, cfg, adv, y, lora)[0].item()
     l_ref = O.loss_and_input_grad(w, cfg, ref, y, lora)[0].item()
@@ -196,7 +201,7 @@ def test_pgd_attack_matches_oracle_trajectory():
     import os
     os.environ["VITLORA_NO_GRAPH"] = "1"
     try:
-        eng2 = make_engine(cfg, w, lora)
+        eng2 = make_engine(cfg, w, lora, precision=prec)
         adv2 = eng2.pgd_attack(x.cuda(), y.cuda(), eps, alpha, steps, random_start=False).cpu()
     finally:
         os.environ.pop("VITLORA_NO_GRAPH")
@@ -221,17 +226,17 @@ def test_pgd_random_start_is_seeded_and_bounded():
     assert abs(u.mean().item()) < 0.02 and abs(u.std().item() - 3 ** -0.5) < 0.02
 
 
-def test_lora_train_grads():
+@pytest.mark.parametrize("prec", PRECS)
+def test_lora_train_grads(prec):
     cfg, w, lora, x, y = make_case(batch=4, targets=("q", "k", "v", "o", "fc1", "fc2"))
-    eng = make_engine(cfg, w, lora)
+    eng = make_engine(cfg, w, lora, precision=prec)
     xn = O.normalise(x)
     logits = eng.forward(xn.cuda(), normalise=False, train=True)
     loss = eng.loss_ce(y.cuda())
     _, gp = eng.backward(False, True)
     torch.cuda.synchronize()
     l_ref, lg_ref, grads = O.lora_train_grads(w, cfg, xn, y, lora)
-    l_sim, _, grads_sim = O.lora_train_grads(w, cfg, xn, y, lora, sim16=True)
-    assert abs(loss.item() - l_ref.item()) < 1e-2 * abs(l_ref.item())
+    assert abs(loss.item() - l_ref.item()) < TOL_ACT[prec] * abs(l_ref.item())
     # walk the flat layout: same order as the library (layer, target) -> A, B ; classifier
     flat = eng.flat
     base = flat.data_ptr()
@@ -242,23 +247,23 @@ def test_lora_train_grads():
                 v = eng.param(i, t, which)
                 off = (v.data_ptr() - base) // 4
                 got = gp[off:off + v.numel()].view(v.shape).cpu()
-                e_sim = rel_l2(got, grads_sim[(which, i, t)])
                 e_ref = rel_l2(got, grads[(which, i, t)])
-                worst = max(worst, e_sim)
-                assert e_sim < 1.5e-2 and e_ref < 3e-2, (i, t, which, e_sim, e_ref)
+                worst = max(worst, e_ref)
+                assert e_ref < TOL_GRAD[prec], (i, t, which, e_ref)
     for which in ("weight", "bias"):
         v = eng.param(-1, "", which)
         off = (v.data_ptr() - base) // 4
         got = gp[off:off + v.numel()].view(v.shape).cpu()
-        assert rel_l2(got, grads[("cls", which)]) < 1e-2
+        assert rel_l2(got, grads[("cls", which)]) < TOL_GRAD[prec]
 
 
-def test_lora_dropout_train_mode_matches_oracle_with_same_masks():
+@pytest.mark.parametrize("prec", PRECS)
+def test_lora_dropout_train_mode_matches_oracle_with_same_masks(prec):
     """lora_dropout > 0 (the reference trains with 0.1, train_loras.py:79): the HIP path's masks are
     read back and handed to the oracle, so the stochastic op is checked exactly."""
     cfg, w, lora, x, y = make_case(batch=4, targets=("q", "k", "v", "o", "fc1", "fc2"))
     p = 0.25
-    eng = make_engine(cfg, w, lora, dropout=p)
+    eng = make_engine(cfg, w, lora, dropout=p, precision=prec)
     eng.set_dropout_seed(77)
     xn = O.normalise(x)
     logits = eng.forward(xn.cuda(), normalise=False, train=True)
@@ -271,7 +276,7 @@ def test_lora_dropout_train_mode_matches_oracle_with_same_masks():
     assert abs(keep - (1 - p)) < 0.02 and torch.allclose(m0[m0 > 0], torch.tensor(1 / (1 - p)))
     assert not torch.equal(masks[(0, "qkv")], masks[(1, "qkv")]) and not torch.equal(masks[(0, "qkv")], masks[(0, "o")])
     l_ref, lg_ref, grads = O.lora_train_grads(w, cfg, xn, y, lora, drop_masks=masks)
-    assert rel_l2(logits.cpu(), lg_ref) < TOL_FP32
+    assert rel_l2(logits.cpu(), lg_ref) < TOL_ACT[prec]
     # without the masks the oracle must NOT match: the masks really were applied
     assert rel_l2(logits.cpu(), O.vit_forward(w, cfg, xn, lora)) > 1.5 * rel_l2(logits.cpu(), lg_ref)
     base = eng.flat.data_ptr()
@@ -281,12 +286,12 @@ def test_lora_dropout_train_mode_matches_oracle_with_same_masks():
                 v = eng.param(i, t, which)
                 off = (v.data_ptr() - base) // 4
                 got = gp[off:off + v.numel()].view(v.shape).cpu()
-                assert rel_l2(got, grads[(which, i, t)]) < 3e-2, (i, t, which)
+                assert rel_l2(got, grads[(which, i, t)]) < TOL_GRAD[prec], (i, t, which)
     # a new forward draws new masks; eval-mode forward ignores dropout
     eng.forward(xn.cuda(), normalise=False, train=True)
     assert not torch.equal(eng.dropout_mask(0, "qkv", 4).cpu(), m0)
     ev = eng.forward(xn.cuda(), normalise=False, train=False).cpu()
-    assert rel_l2(ev, O.vit_forward(w, cfg, xn, lora)) < TOL_FP32
+    assert rel_l2(ev, O.vit_forward(w, cfg, xn, lora)) < TOL_ACT[prec]
 
 
 def test_adam_and_quantiser():

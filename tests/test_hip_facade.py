@@ -15,35 +15,48 @@ from test_oracle_golden import load_case
 pytestmark = pytest.mark.gpu
 
 
-def _model(cfg, w, num_labels=None):
+PRECS = ["f16", "f32"]
+TOL_ACT = {"f16": 4e-3, "f32": 1e-4}       # north_star: 1e-2 (16-bit) / 1e-3 (fp32)
+TOL_GRAD = {"f16": 6e-3, "f32": 1e-4}
+
+
+def _model(cfg, w, num_labels=None, precision="f16"):
     P = pkg()
     arch = P.ArchConfig(image_size=cfg.image_size, patch_size=cfg.patch_size, hidden=cfg.hidden, layers=cfg.layers,
                         heads=cfg.heads, mlp=cfg.mlp, num_labels=cfg.num_labels, ln_eps=cfg.ln_eps)
-    m = P.create_vit_model(cfg.num_labels, arch=arch)
+    m = P.create_vit_model(cfg.num_labels, arch=arch, precision=precision)
     m.load_state_dict(w)
     return m.eval()
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("name", ["tiny17", "tiny197", "vitb"])
-def test_golden_reference_fgsm_and_logits(name):
-    """HIP path vs what the REFERENCE produced (HF ViT logits, input gradient, FGSM decisions)."""
+def test_golden_reference_fgsm_and_logits(name, prec):
+    """HIP path vs what the REFERENCE produced (HF ViT logits, loss, input gradient, FGSM decisions: G1-G3)."""
     P = pkg()
     cfg, w, x, y, z = load_case(name)
-    model = _model(cfg, w)
+    model = _model(cfg, w, precision=prec)
     mean, std = P.get_normalization("google_vit")
     mt, st = torch.tensor(mean).view(1, 3, 1, 1), torch.tensor(std).view(1, 3, 1, 1)
     logits = P.LogitsModel(model)(((x - mt) / st).cuda()).cpu()
-    assert rel_l2(logits, torch.from_numpy(z["logits"])) < 1e-2          # north_star bf16 tolerance
+    assert rel_l2(logits, torch.from_numpy(z["logits"])) < TOL_ACT[prec]
+    # the reference's own input gradient (perturbed.grad of whitebox_attacks.py:30-32)
+    eng = model._engine()
+    eng.forward(x.cuda(), normalise=True)
+    loss = eng.loss_ce(y.cuda()).item()
+    gx, _ = eng.backward(True, False, tuple(x.shape))
+    g_ref = torch.from_numpy(z["grad"])
+    assert abs(loss - float(z["loss"])) < TOL_ACT[prec] * float(z["loss"])
+    assert rel_l2(gx.cpu(), g_ref) < TOL_GRAD[prec], rel_l2(gx.cpu(), g_ref)
     adv = P.batched_fgsm_attack(model, x.cuda(), y.cuda(), float(z["eps"]), mt.cuda(), st.cuda()).cpu()
     assert abs((adv - x).abs().max().item() - float(z["adv_absmax"])) < 1e-6
     ref_sign = torch.from_numpy(z["adv_minus_x_sign"])
-    g_ref = torch.from_numpy(z["grad"])
     sign = torch.sign(adv - x).to(torch.int8)
-    # decisions may differ only where the reference gradient is inside the bf16 noise floor
+    # decisions may differ only where the reference gradient is inside the rounding noise
     big = (g_ref.abs() > 0.1 * g_ref.abs().mean()) & (ref_sign != 0)
     agree_big = (sign[big] == ref_sign[big]).float().mean().item()
     agree_all = (sign == ref_sign).float().mean().item()
-    assert agree_big > 0.97 and agree_all > 0.90, (agree_big, agree_all)
+    assert agree_big > 0.9999 and agree_all > (0.998 if prec == "f16" else 0.9999), (agree_big, agree_all)
 
 
 def test_reference_style_autograd_fgsm():
@@ -59,8 +72,8 @@ def test_reference_style_autograd_fgsm():
     loss = F.cross_entropy(P.get_model_output(outputs), y.cuda())
     loss.backward()
     l_ref, g_ref, _ = O.loss_and_input_grad(w, cfg, x, y)
-    assert abs(loss.item() - l_ref.item()) < 1e-2 * abs(l_ref.item())
-    assert rel_l2(perturbed.grad.cpu(), g_ref) < 2e-2
+    assert abs(loss.item() - l_ref.item()) < TOL_ACT["f16"] * abs(l_ref.item())
+    assert rel_l2(perturbed.grad.cpu(), g_ref) < TOL_GRAD["f16"]
 
 
 def test_pgd_class_canonical_and_torchattacks_compat():
@@ -78,7 +91,7 @@ def test_pgd_class_canonical_and_torchattacks_compat():
     d, dr = (adv - x) * st, (ref - x) * st            # perturbation in the attack's own space
     assert d.abs().max().item() <= eps + 1e-5
     agree = (torch.sign(d) == torch.sign(dr)).float().mean().item()
-    assert agree > 0.9, agree
+    assert agree > 0.97, agree
     # no normalisation registered: model consumes the adversarial image directly
     atk2 = P.PGD(P.LogitsModel(model), eps=eps, alpha=alpha, steps=steps, random_start=False)
     adv2 = atk2(x.cuda(), y.cuda()).cpu()
@@ -86,12 +99,12 @@ def test_pgd_class_canonical_and_torchattacks_compat():
     for _ in range(steps):
         _, g, _ = O.loss_and_input_grad(w, cfg, adv_o, y, normalised=True)
         adv_o = O.pgd_step(adv_o, x, g, eps, alpha)
-    assert (torch.sign(adv2 - x) == torch.sign(adv_o - x)).float().mean().item() > 0.9
+    assert (torch.sign(adv2 - x) == torch.sign(adv_o - x)).float().mean().item() > 0.97
     # FGSM class == batched_fgsm_attack when the same normalisation is registered
     f = P.FGSM(P.LogitsModel(model), eps=eps)
     a1 = f(O.normalise(x).cuda(), y.cuda()).cpu()      # no set_normalization_used: model fed as is
     a_ref = torch.clamp(O.normalise(x) + eps * torch.sign(O.loss_and_input_grad(w, cfg, O.normalise(x), y, normalised=True)[1]), 0, 1)
-    assert (torch.sign(a1 - O.normalise(x)) == torch.sign(a_ref - O.normalise(x))).float().mean().item() > 0.9
+    assert (torch.sign(a1 - O.normalise(x)) == torch.sign(a_ref - O.normalise(x))).float().mean().item() > 0.99
 
 
 def test_peft_roundtrip_and_merge(tmp_path):
@@ -108,9 +121,8 @@ def test_peft_roundtrip_and_merge(tmp_path):
     for (i, t), (A, B) in lora.ab.items():
         eng.param(i, t, "A").copy_(A)
         eng.param(i, t, "B").copy_(B)
-    pm._vit.mark_dirty()
     l1 = pm.base_model(pixel_values=xn).logits.detach().cpu()
-    assert rel_l2(l1, O.vit_forward(w, cfg, O.normalise(x), lora)) < 1e-2
+    assert rel_l2(l1, O.vit_forward(w, cfg, O.normalise(x), lora)) < TOL_ACT["f16"]
     d = str(tmp_path / "adapter")
     pm.save_pretrained(d)
     assert sorted(os.listdir(d)) == ["adapter_config.json", "adapter_model.safetensors"]
@@ -125,7 +137,7 @@ def test_peft_roundtrip_and_merge(tmp_path):
     assert torch.allclose(l1, l2, rtol=0, atol=1e-5)
     merged = pm2.merge_and_unload()
     l3 = merged(xn).logits.detach().cpu()
-    assert rel_l2(l3, l1) < 1e-2
+    assert rel_l2(l3, l1) < TOL_ACT["f16"]
 
 
 def test_lora_training_steps_match_oracle():
@@ -139,7 +151,6 @@ def test_lora_training_steps_match_oracle():
     for (i, t), (A, B) in lora.ab.items():
         eng.param(i, t, "A").copy_(A)
         eng.param(i, t, "B").copy_(B)
-    pm._vit.mark_dirty()
     pm.train()
     crit = torch.nn.CrossEntropyLoss()
     lr = 1e-3
@@ -174,7 +185,7 @@ def test_lora_training_steps_match_oracle():
             else:
                 A, B = ol.ab[key[1:]]
                 ol.ab[key[1:]] = (p2, B) if key[0] == "A" else (A, p2)
-    assert all(abs(a - b) < 2e-2 * abs(b) for a, b in zip(losses_hip, losses_ref)), (losses_hip, losses_ref)
+    assert all(abs(a - b) < 5e-3 * abs(b) for a, b in zip(losses_hip, losses_ref)), (losses_hip, losses_ref)
     assert losses_hip[-1] < losses_hip[0]
     # parameters after 3 Adam steps (Adam normalises the step: compare the direction of the update)
     for (i, t) in list(lora.ab.keys())[:6]:
@@ -182,7 +193,7 @@ def test_lora_training_steps_match_oracle():
             got = eng.param(i, t, which).cpu() - lora.ab[(i, t)][idx]
             want = ol.ab[(i, t)][idx] - lora.ab[(i, t)][idx]
             cos = float((got * want).sum() / (got.norm() * want.norm() + 1e-30))
-            assert cos > 0.9, (i, t, which, cos)
+            assert cos > 0.97, (i, t, which, cos)
 
 
 def test_sequential_adapter_merge_matches_summed_update(tmp_path):
@@ -197,7 +208,6 @@ def test_sequential_adapter_merge_matches_summed_update(tmp_path):
         for (i, t), (A, B) in lora.ab.items():
             eng.param(i, t, "A").copy_(A)
             eng.param(i, t, "B").copy_(B)
-        pm._vit.mark_dirty()
         d = str(tmp_path / f"adapter{k}")
         pm.save_pretrained(d)
         dirs.append(d)
@@ -211,7 +221,7 @@ def test_sequential_adapter_merge_matches_summed_update(tmp_path):
             key = f"vit.encoder.layer.{i}." + dict(O.LINEAR_MODULES)[t] + ".weight"
             w2[key] = w2[key] + lora.scaling * (B @ A)
     ref = O.vit_forward(w2, cfg, xn, None)
-    assert rel_l2(got, ref) < 1e-2
+    assert rel_l2(got, ref) < TOL_ACT["f16"]
     # and the merge changed the model (both adapters matter)
     assert rel_l2(ref, O.vit_forward(w, cfg, xn, None)) > 5e-2
     # accuracy / weighted-F1 helper against hand-computed values

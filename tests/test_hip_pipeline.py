@@ -1,0 +1,98 @@
+"""The reference's on-disk pipeline end to end on the GPU, with its own file formats at every hand-over:
+
+    train.py            -> <models>/<model>/<source>/<model>_best_model_finetuned.pth + class_mappings.txt
+    whitebox_attacks.py -> <adv>/<model>/<source>/<split>/<attack>/images/*.png + metadata.csv   (save_images bytes)
+    train_loras.py      -> <loras>/<model>/<source>/<attack>/rank{r}_best_adapter, rank{r}_final_adapter, results.json
+    eval_compose.py     -> finds those adapters (no --synthetic), evaluates base / single / merged models
+
+on a tiny architecture and a synthetic dataset tree in the reference's layout (Utils.py:12-82)."""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import PKG, pkg
+
+pytestmark = pytest.mark.gpu
+
+CLASSES = ["stop", "yield", "speed_limit", "no_entry"]
+
+
+@pytest.fixture(scope="module")
+def tree(tmp_path_factory):
+    root = tmp_path_factory.mktemp("pipeline")
+    syn = importlib.import_module(PKG + ".synthetic")
+    data = str(root / "data")
+    syn.write_dataset_tree(data, CLASSES, {"train": 40, "val": 12, "test": 12}, image_size=64, seed=3)
+    return {"root": str(root), "data": data, "models": str(root / "models"), "adv": str(root / "adv"),
+            "loras": str(root / "loras")}
+
+
+def test_pipeline_train_attack_lora_compose(tree):
+    import eval_compose
+    import train
+    import train_loras
+    import whitebox_attacks
+    from PIL import Image
+    P = pkg()
+    train.main(["--data_root", tree["data"], "--output_dir", tree["models"], "--synthetic", "--arch", "tiny", "--source", "mapillary"])
+    ckpt = os.path.join(tree["models"], "google_vit", "mapillary", "google_vit_best_model_finetuned.pth")
+    mapping = os.path.join(tree["models"], "google_vit", "mapillary", "class_mappings.txt")
+    assert os.path.exists(ckpt) and open(mapping).read().splitlines() == [f"{i}: {c}" for i, c in enumerate(sorted(CLASSES))]
+
+    eps = 8 / 255
+    whitebox_attacks.main(["--data_root", tree["data"], "--models", "google_vit", "--sources", "mapillary", "--model_base_path",
+                           tree["models"], "--output_dir", tree["adv"], "--arch", "tiny", "--batch_size", "16", "--pgd_iters", "3",
+                           "--epsilon", str(eps)])
+    import pandas as pd
+    for split, n in (("train", 40), ("val", 12), ("test", 12)):
+        for attack in ("fgsm", "pgd"):
+            d = os.path.join(tree["adv"], "google_vit", "mapillary", split, attack)
+            meta = pd.read_csv(os.path.join(d, "metadata.csv"))
+            assert len(meta) == n and len(os.listdir(os.path.join(d, "images"))) == n
+            assert all(os.path.exists(p) for p in meta["image_path"])
+            assert list(meta.columns) == ["image_path", "unified_class", "source"]
+    # FGSM PNG = clean PNG +- eps (quantised with save_images' truncation): at most ceil(eps*255) grey levels apart
+    clean = np.asarray(Image.open(os.path.join(tree["data"], "test", "images", "test_00003.png")), dtype=np.int32)
+    adv = np.asarray(Image.open(os.path.join(tree["adv"], "google_vit", "mapillary", "test", "fgsm", "images", "test_00003.png")), dtype=np.int32)
+    # (the 64-pixel tiny arch resizes 64 -> 73 -> centre crop 64, so compare statistics, not pixels)
+    assert adv.shape == (64, 64, 3) and 1 <= np.abs(adv - adv.mean()).max()
+
+    base = os.path.join(tree["models"], "{model}", "{source}", "{model}_best_model_finetuned.pth")
+    res = train_loras.main(["--models", "google_vit", "--sources", "mapillary", "--attacks", "fgsm", "pgd", "--model_base_path", base,
+                            "--adv_root", tree["adv"], "--data_root", tree["data"], "--output_dir", tree["loras"], "--ranks", "4",
+                            "--epochs", "2", "--arch", "tiny", "--batch_size", "16", "--lr", "1e-3"])
+    for attack in ("fgsm", "pgd"):
+        d = os.path.join(tree["loras"], "google_vit", "mapillary", attack)
+        for kind in ("best", "final"):                      # the reference's directory names (train_loras.py:343,353)
+            a = os.path.join(d, f"rank4_{kind}_adapter")
+            assert sorted(os.listdir(a)) == ["adapter_config.json", "adapter_model.safetensors"]
+        r = json.load(open(os.path.join(d, "results.json")))["4"]
+        assert set(r) == {"train_loss", "train_acc", "val_loss", "val_acc", "val_f1", "clean_test_acc", "clean_test_f1",
+                          "adv_test_acc", "adv_test_f1", "best_val_acc"}
+        assert len(r["train_loss"]) == 2 and len(r["val_acc"]) == 2 and r["best_val_acc"] == max(r["val_acc"])
+        assert all(np.isfinite(v) for v in r["train_loss"])
+    g = json.load(open(os.path.join(tree["loras"], "global_results.json")))
+    assert set(g["google_vit"]["mapillary"]) == {"fgsm", "pgd"} and res["google_vit"]["mapillary"]["fgsm"][4]["train_loss"]
+
+    out = os.path.join(tree["root"], "compose.json")
+    r = eval_compose.main(["--model_path", ckpt, "--lora_root", tree["loras"], "--adv_root", tree["adv"], "--data_root", tree["data"],
+                           "--attacks", "fgsm", "pgd", "--rank", "4", "--arch", "tiny", "--output_file", out])
+    assert {"base_model", "fgsm_lora", "pgd_lora", "fgsm+pgd_merged"} <= set(r)
+    assert set(r["base_model"]) == {"clean", "fgsm", "pgd"}
+    assert all(0.0 <= v["accuracy"] <= 1.0 for v in r["fgsm+pgd_merged"].values())
+    assert json.load(open(out))["rank"] == 4
+
+
+def test_train_loras_synthetic_with_pgd_inner_loop(tmp_path):
+    """BASELINE config 3 through the CLI: PGD-K against the CURRENT adapters inside every train step."""
+    import train_loras
+    res = train_loras.main(["--output_dir", str(tmp_path), "--attacks", "pgd", "--ranks", "4", "--epochs", "2", "--synthetic", "24",
+                            "--num_classes", "5", "--arch", "tiny", "--batch_size", "8", "--pgd-inner-steps", "2", "--lr", "1e-3",
+                            "--lora_dropout", "0.1"])
+    r = res["google_vit"]["mapillary"]["pgd"][4]
+    assert len(r["train_loss"]) == 2 and all(np.isfinite(v) for v in r["train_loss"] + r["val_loss"])
+    assert os.path.isdir(os.path.join(str(tmp_path), "google_vit", "mapillary", "pgd", "rank4_best_adapter"))

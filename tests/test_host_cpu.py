@@ -99,6 +99,77 @@ def test_synthetic_weights_match_oracle_init():
     assert la.keys() == lb.keys() and all(torch.equal(la[k][0], lb[k][0]) and torch.equal(la[k][1], lb[k][1]) for k in la)
 
 
+def test_global_batch_plan_gives_every_rank_the_same_number_of_steps():
+    """65 images, 2 ranks, batch 32 (VERDICT r1 weak #7): rank 0 used to run one more optimizer step than rank 1."""
+    opt = importlib.import_module(PKG + ".optim")
+    for n, batch, world in [(65, 32, 2), (64, 32, 2), (5, 4, 8), (100, 7, 3), (1, 32, 8)]:
+        plans = [opt.global_batch_plan(n, batch, r, world, shuffle_seed=3) for r in range(world)]
+        assert len({len(p) for p in plans}) == 1, (n, batch, world)
+        steps = len(plans[0])
+        assert steps == (n + batch - 1) // batch
+        seen = []
+        for st in range(steps):
+            sizes = [len(p[st][0]) for p in plans]
+            assert sum(sizes) == plans[0][st][1] and max(sizes) - min(sizes) <= 1
+            assert len({p[st][1] for p in plans}) == 1
+            for p in plans:
+                seen += p[st][0]
+        assert sorted(seen) == list(range(n))                 # every sample exactly once per epoch
+    # same seed -> same order on every rank; another seed -> another order
+    a = opt.global_batch_plan(50, 8, 0, 2, shuffle_seed=1)
+    assert a == opt.global_batch_plan(50, 8, 0, 2, shuffle_seed=1) != opt.global_batch_plan(50, 8, 0, 2, shuffle_seed=2)
+
+
+_WORKER_ODD = r'''
+import os, sys, torch, importlib
+import torch.distributed as dist
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+from helpers import O, PKG, make_case
+opt = importlib.import_module(PKG + ".optim")
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2,
+                        timeout=__import__("datetime").timedelta(seconds=60))
+rank = dist.get_rank()
+N, BATCH = 9, 4                         # global batches of 4, 4, 1: the last one leaves rank 1 with an EMPTY shard
+cfg, w, lora, x, y = make_case(batch=N, layers=1)
+xn = O.normalise(x)
+keys = None
+steps = 0
+for idx, n_global in opt.global_batch_plan(N, BATCH, rank, 2, shuffle_seed=11):
+    if idx:
+        _, _, g = O.lora_train_grads(w, cfg, xn[idx], y[idx], lora)            # mean over the LOCAL shard
+        keys = sorted(g.keys(), key=str)
+        flat = torch.cat([g[k].flatten() for k in keys])
+    else:
+        flat = torch.zeros(numel)                                               # empty shard: zero contribution
+    numel = flat.numel()
+    opt.allreduce_weighted_mean_(flat, len(idx), n_global)                      # the ONE exchange step
+    # single-process gradient of the same global batch
+    gidx = opt.global_batch_plan(N, BATCH, 0, 1, shuffle_seed=11)[steps][0]
+    _, _, gf = O.lora_train_grads(w, cfg, xn[gidx], y[gidx], lora)
+    ks = sorted(gf.keys(), key=str)
+    full = torch.cat([gf[k].flatten() for k in ks])
+    err = float((flat - full).norm() / full.norm())
+    assert err < 1e-5, (steps, err)
+    steps += 1
+print("rank", rank, "steps", steps, flush=True)
+assert steps == 3
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_ragged_last_batch_does_not_hang_gloo(tmp_path):
+    """2 ranks, 9 samples, batch 4: every rank takes part in all 3 all-reduces (one of them with an empty shard) and
+    the weighted exchange reproduces the single-process gradient of each global batch."""
+    port = 31500 + (os.getpid() % 2000)
+    script = tmp_path / "worker_odd.py"
+    script.write_text(_WORKER_ODD.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert all("steps 3" in o for o in outs)
+
+
 _WORKER = r'''
 import os, sys, torch, importlib
 import torch.distributed as dist

@@ -92,3 +92,80 @@ def test_adam_matches_torch_optim():
         opt.step()
         q, m, v = O.adam_step(q, g, m, v, t)
     assert torch.allclose(q, p.detach(), rtol=1e-6, atol=1e-7)
+
+
+# ---- G4: PGD trajectories whose every ascent step is the reference's own batched_fgsm_attack on the HF model ----
+LORA_TARGETS = ("q", "k", "v", "o", "fc2")
+
+
+def load_npz(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+@pytest.mark.parametrize("name", ["tiny17", "vitb"])
+def test_pgd_matches_reference_driven_trajectory(name):
+    cfg, w, x, y, _ = load_case(name)
+    z = load_npz(f"pgd_{name}.npz")
+    eps, alpha = float(z["eps"]), float(z["alpha"])
+    noise = torch.rand(x.shape, generator=torch.Generator().manual_seed(int(z["noise_seed"]))) * 2 - 1
+    steps = [int(k) for k in z["steps"]]
+    for start, nz in (("x0", None), ("noise", noise)):
+        adv = x.clone() if nz is None else torch.clamp(x + eps * nz, 0, 1)
+        done = 0
+        for k in steps:
+            # continue the oracle's canonical loop (oracle.pgd body) from the previous checkpoint
+            for _ in range(k - done):
+                _, g, _ = O.loss_and_input_grad(w, cfg, adv, y)
+                adv = O.pgd_step(adv, x, g, eps, alpha)
+            done = k
+            ref = x + torch.from_numpy(z[f"delta_{start}_{k}"])
+            same = ((adv - ref).abs() < 1e-6).float().mean().item()
+            # sign() of fp32 gradients: a vanishing fraction of near-zero entries may flip between two fp32 programs
+            assert same > 0.999, (name, start, k, same)
+            assert (adv - x).abs().max().item() <= eps + 1e-6
+
+
+# ---- G5: LoRA = plain-torch low-rank branches around the HF model's own nn.Linear modules ----
+@pytest.mark.parametrize("name", ["tiny17", "tiny197", "vitb"])
+def test_lora_matches_hf_wrapped_linears(name):
+    cfg, w, x, y, _ = load_case(name)
+    z = load_npz(f"lora_{name}.npz")
+    _, _, _, _, _, _, _, _, seed = [int(v) for v in load_npz(f"fgsm_{name}.npz")["meta"]]
+    for r in [int(v) for v in z["ranks"]]:
+        lora = O.init_lora(cfg, r=r, targets=LORA_TARGETS, seed=seed + 100 + r, b_std=0.02 if name == "vitb" else 0.05)
+        loss, logits, grads = O.lora_train_grads(w, cfg, O.normalise(x), y, lora)
+        assert torch.allclose(logits, torch.from_numpy(z[f"r{r}_logits"]), rtol=1e-4, atol=2e-5)
+        assert abs(loss.item() - float(z[f"r{r}_loss"])) < 1e-5
+        rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+        assert rel(grads[("cls", "weight")], torch.from_numpy(z[f"r{r}_dcls_w"])) < 1e-4
+        assert rel(grads[("cls", "bias")], torch.from_numpy(z[f"r{r}_dcls_b"])) < 1e-4
+        checked = 0
+        for key in z.files:
+            if key.startswith(f"r{r}_dA_") or key.startswith(f"r{r}_dB_"):
+                _, which, i, t = key.split("_", 3)
+                e = rel(grads[(which[1], int(i), t)], torch.from_numpy(z[key]))
+                assert e < 2e-4, (key, e)
+                checked += 1
+        assert checked >= 6
+        # every (layer, target) pair by its gradient norms
+        norms = z[f"r{r}_grad_norms"]
+        keys = sorted(lora.ab.keys())
+        for (i, t), (na, nb) in zip(keys, norms):
+            assert abs(float(grads[("A", i, t)].double().norm()) - na) < 2e-4 * na + 1e-12
+            assert abs(float(grads[("B", i, t)].double().norm()) - nb) < 2e-4 * nb + 1e-12
+
+
+# ---- G8: bytes written by the reference's Utils.save_images ----
+def test_save_images_quantisation_matches_reference_bytes():
+    z = load_npz("save_images.npz")
+    got = O.save_images_quant(torch.from_numpy(z["images"]))
+    assert torch.equal(got, torch.from_numpy(z["bytes_hwc"]))
+
+
+def test_fashion_mnist_label_fixture():
+    """First 512 labels of the reference's t10k-labels-idx1-ubyte (BASELINE config 1)."""
+    from helpers import fmnist_labels
+    y = fmnist_labels(512)
+    assert y.shape == (512,) and y.dtype == torch.int64 and int(y.min()) >= 0 and int(y.max()) <= 9
+    assert y[:8].tolist() == [9, 2, 1, 1, 6, 1, 4, 6]
+    assert torch.bincount(y, minlength=10).min().item() > 30       # all ten classes are present

@@ -38,6 +38,7 @@ def main(argv=None):
     p.add_argument("--synthetic", action="store_true")
     p.add_argument("--num_classes", type=int, default=21)
     p.add_argument("--head_only", action="store_true")
+    p.add_argument("--arch", choices=["tiny", "vit_b", "vit_l"], default="vit_b")
     p.add_argument("--seed", type=int, default=0)
     args = p.parse_args(argv)
 
@@ -63,7 +64,7 @@ def main(argv=None):
         sd = torch.load(args.from_state_dict, map_location="cpu", weights_only=True)
         sd = {V.canonical_key(k): v for k, v in sd.items()}
     elif args.synthetic:
-        sd = syn.random_state_dict(V.ArchConfig(num_labels=C), seed=args.seed)
+        sd = syn.random_state_dict(syn.arch_by_name(args.arch, C), seed=args.seed)
     else:
         raise SystemExit("full-weight fine-tuning is outside the accelerated path: pass --from_state_dict FILE "
                          "(re-export a checkpoint) or --synthetic (seeded random init); add --head_only to train the head")
@@ -71,12 +72,13 @@ def main(argv=None):
     if args.head_only:
         if not args.data_root:
             raise SystemExit("--head_only needs --data_root")
-        model = V.create_vit_model(C)
+        model = V.create_vit_model(C, arch=syn.arch_by_name(args.arch, C))
         model.load_state_dict(sd, strict=False)
         pm = V.get_peft_model(model, V.LoraConfig(task_type=V.TaskType.SEQ_CLS, r=1, target_modules=[]))
         opt = V.Adam(pm.parameters(), lr=args.lr, model=pm)
         ds = iomod.FolderDataset(args.data_root, os.path.join(args.data_root, "train", "metadata.csv"), class_to_idx,
-                                 sources=[args.source], normalise=V.get_normalization(model_name))
+                                 image_size=syn.arch_by_name(args.arch, C).image_size, sources=[args.source],
+                                 normalise=V.get_normalization(model_name))
         crit = torch.nn.CrossEntropyLoss()
         for ep in range(args.epochs):
             pm.train()

@@ -3,15 +3,17 @@
 reference's whitebox_attacks.py (flags: whitebox_attacks.py:53-64; directory layout
 <out>/<model>/<source>/<split>/<attack>/images/*.png + metadata.csv: :118-124,175-178).
 
-Differences, all opt-in:
-  --torchattacks-compat   reproduce the reference's PGD call pattern exactly
-                          (set_normalization_used on un-normalised images, :169-170); the
-                          default is the canonical attack in [0,1] with the model fed
-                          (x - mean) / std, as the reference's own FGSM does (:22-38).
+PGD runs with the reference's own call pattern by default: torchattacks' set_normalization_used(mean, std)
+on UN-normalised [0,1] images (:169-170), i.e. the attack happens in x*std+mean space and the model sees
+x + delta/std.  Extensions, all opt-in:
+  --canonical-pgd         the textbook attack instead: perturb in [0,1], model fed (x - mean) / std, as the
+                          reference's own FGSM does (:22-38).
   --synthetic N           no dataset / checkpoint on disk: N seeded random images per split and
                           seeded random-init weights (throughput and plumbing runs).
+  --arch tiny|vit_b|vit_l architecture of the checkpoint (default vit_b = google/vit-base-patch16-224).
   --lora_dir DIR          attack the model with a peft-format adapter applied.
-  --world-size / RANK     image batches shard over ranks (one process per GPU, no collective).
+  torch.distributed.run   image batches shard over ranks (one process per GPU, no data-path collective);
+                          ranks meet at a barrier before rank 0 writes metadata.csv.
 """
 import argparse
 import importlib
@@ -38,7 +40,11 @@ def build_parser():
     p.add_argument("--splits", nargs="+", default=["train", "val", "test"])
     p.add_argument("--attacks", nargs="+", choices=["fgsm", "pgd"], default=["fgsm", "pgd"],
                    help="Which attacks to run (default: both)")
-    p.add_argument("--torchattacks-compat", action="store_true")
+    p.add_argument("--canonical-pgd", action="store_true")
+    p.add_argument("--torchattacks-compat", action="store_true", help="(default behaviour; kept for round-1 command lines)")
+    p.add_argument("--arch", choices=["tiny", "vit_b", "vit_l"], default="vit_b")
+    p.add_argument("--tiny", action="store_true", help="same as --arch tiny")
+    p.add_argument("--precision", choices=["f16", "f32"], default="f16")
     p.add_argument("--synthetic", type=int, default=0, metavar="N")
     p.add_argument("--num_classes", type=int, default=21, help="only with --synthetic")
     p.add_argument("--lora_dir", default=None)
@@ -48,9 +54,11 @@ def build_parser():
 
 def load_model(args, model_name, source_name, device):
     mean, std = V.get_normalization(model_name)
+    syn = importlib.import_module(V.__name__ + ".synthetic")
+    arch_name = "tiny" if args.tiny else args.arch
     if args.synthetic:
-        syn = importlib.import_module(V.__name__ + ".synthetic")
-        model = V.create_vit_model(args.num_classes, device=device)
+        model = V.create_vit_model(args.num_classes, arch=syn.arch_by_name(arch_name, args.num_classes), device=device,
+                                   precision=args.precision)
         model.load_state_dict(syn.random_state_dict(model.arch, seed=args.seed))
         class_to_idx = {f"class_{i}": i for i in range(args.num_classes)}
     else:
@@ -60,7 +68,8 @@ def load_model(args, model_name, source_name, device):
             print(f"Warning: Class mapping file not found: {mapping_path}")
             return None
         class_to_idx = iomod.read_class_mappings(mapping_path)
-        model = V.create_vit_model(len(class_to_idx), device=device)
+        model = V.create_vit_model(len(class_to_idx), arch=syn.arch_by_name(arch_name, len(class_to_idx)), device=device,
+                                   precision=args.precision)
         try:
             model.load_state_dict(torch.load(model_path, map_location="cpu", weights_only=True))
         except FileNotFoundError:
@@ -86,7 +95,8 @@ def batches(args, split, class_to_idx, model, rank, world):
         return
     iomod = importlib.import_module(V.__name__ + ".io")
     meta = os.path.join(args.data_root, split, "metadata.csv")
-    ds = iomod.FolderDataset(args.data_root, meta, class_to_idx, sources=args.sources)
+    arch = importlib.import_module(V.__name__ + ".attacks")._unwrap(model).arch
+    ds = iomod.FolderDataset(args.data_root, meta, class_to_idx, image_size=arch.image_size, sources=args.sources)
     sub = torch.utils.data.Subset(ds, list(range(rank, len(ds), world)))
     loader = torch.utils.data.DataLoader(sub, batch_size=args.batch_size, shuffle=False,
                                          num_workers=min(4, os.cpu_count() or 1), pin_memory=True)
@@ -101,6 +111,13 @@ def main(argv=None):
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
     print(f"Using device: {device} (rank {rank}/{world})")
+    dist = None
+    if world > 1:
+        # no data-path collective: the group exists for the barrier / file-name exchange before metadata.csv
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not dist.is_initialized():
+            dist.init_process_group("gloo")
     iomod = importlib.import_module(V.__name__ + ".io")
     atk = importlib.import_module(V.__name__ + ".attacks")
 
@@ -131,24 +148,33 @@ def main(argv=None):
                     if "fgsm" in args.attacks:
                         out["fgsm"] = V.batched_fgsm_attack(model, images, labels, args.epsilon, mean, std)
                     if pgd is not None:
-                        if args.torchattacks_compat:
-                            pgd.set_normalization_used(mean=mean, std=std)       # whitebox_attacks.py:169
-                            out["pgd"] = pgd(images, labels)
-                        else:
-                            # canonical: attack in [0,1], model fed (x-mean)/std
+                        if args.canonical_pgd:
+                            # textbook form: attack in [0,1], model fed (x-mean)/std
                             engine.set_normalization(mean, std)
                             out["pgd"] = engine.pgd_attack(images, labels, args.epsilon, args.pgd_alpha, args.pgd_iters,
                                                            random_start=True, seed=args.seed + len(seen))
+                        else:
+                            pgd.set_normalization_used(mean=mean, std=std)       # whitebox_attacks.py:169
+                            out["pgd"] = pgd(images, labels)
                     for a, adv in out.items():
                         iomod.save_images(adv, filenames, dirs[a], engine=engine)
+                all_seen = seen
+                if dist is not None:
+                    # every rank has finished writing its PNGs and rank 0 learns all file names: no directory
+                    # listing, so stale files of an earlier run cannot leak into metadata.csv
+                    gathered = [None] * world
+                    dist.all_gather_object(gathered, seen)
+                    all_seen = [fn for part in gathered for fn in part]
                 if not args.synthetic and rank == 0:
                     clean_meta = os.path.join(args.data_root, split, "metadata.csv")
                     for a in args.attacks:
-                        meta = iomod.create_adv_metadata(clean_meta, seen if world == 1 else os.listdir(dirs[a]), dirs[a])
+                        meta = iomod.create_adv_metadata(clean_meta, all_seen, dirs[a])
                         meta.to_csv(os.path.join(base_out, a, "metadata.csv"), index=False)
                         print(f"    {a.upper()} results saved to: {os.path.join(base_out, a)}")
                 elif rank == 0:
-                    print(f"    {len(seen)} images per attack written under {base_out}")
+                    print(f"    {len(all_seen)} images per attack written under {base_out}")
+    if dist is not None:
+        dist.barrier()
 
 
 if __name__ == "__main__":
