@@ -826,7 +826,15 @@ int vl_pgd_attack(vl_model* m, const float* x0, const int64_t* labels, int batch
             hipGraphExec_t exec = nullptr;
             for (GraphEntry& g : m->graphs)
                 if (g.B == batch && g.eps == eps && g.alpha == alpha) { exec = g.exec; break; }
+            int first = 0;
             if (!exec) {
+                // The iteration is run once EAGERLY before it is captured (it is the attack's first step, nothing is
+                // wasted): a kernel whose code object is first touched inside a stream capture did not make it into
+                // the graph reliably on ROCm 7.2 (replays then differed from the eager result until every kernel had
+                // been launched once outside capture; tools/determinism_probe2.py).
+                if ((rc = pgd_iteration(m, w.stage_x0, w.stage_labels, batch, eps, alpha, w.stage_adv, s))) return rc;
+                if ((rc = check_launch("vl_pgd_attack"))) return rc;
+                first = 1;
                 hipGraph_t graph = nullptr;
                 // capture on a private stream (the caller's may be the legacy default stream, which cannot
                 // capture); nothing executes during capture, the graph is launched on the caller's stream.
@@ -844,7 +852,7 @@ int vl_pgd_attack(vl_model* m, const float* x0, const int64_t* labels, int batch
                 m->graphs.push_back({batch, eps, alpha, exec});
                 m->n_captures++;
             }
-            for (int i = 0; i < steps; ++i) HIPCHK(hipGraphLaunch(exec, s));
+            for (int i = first; i < steps; ++i) HIPCHK(hipGraphLaunch(exec, s));
         }
     }
     HIPCHK(hipMemcpyAsync(adv_out, w.stage_adv, n * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -12,7 +12,7 @@ backbone and the adapters are replicated).  Rank 0 prints ONE JSON line.
 
 Extra objects in that line:
   roofline      the dominant kernel, timed live with HIP events on the launch stream
-                (vl_profile_begin/_report, include/vitlora.h) against the gfx950 dense bf16
+                (vl_profile_begin/_report, include/vitlora.h) against the gfx950 dense fp16 / bf16
                 MFMA peak; plus `path` = whole-path algorithmic FLOP/s and `pgd_step` =
                 the HBM-bound elementwise kernel against the 8 TB/s HBM peak.
   extras        secondary measurements (merged-LoRA attack, one LoRA train step); not `value`.
@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "adapting-pretrained-vision-transformers-with-lora-against-attack-vectors_amd"
 
-PEAK_BF16_DENSE = 2.5e15      # FLOP/s, MI355X_MICROARCH.md chip table (dense, no sparsity)
+PEAK_BF16_DENSE = 2.5e15      # FLOP/s dense (no sparsity), the bf16 / fp16 MFMA peak of MI355X_MICROARCH.md (same rate)
 PEAK_HBM = 8.0e12             # B/s
 
 EPS, ALPHA = 8 / 255, 2 / 255
@@ -141,9 +141,14 @@ def extras(P, syn, arch, args, dev, x, y):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-    tools/pmc_traffic.py; counters cannot be read from inside this process).  None if not on file."""
+    tools/pmc_traffic.py; counters cannot be read from inside this process).  The profile carries a hash of the
+    kernel sources it was taken on: if the sources changed since, the number is OMITTED (None), never quoted stale."""
     try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from pmc_traffic import kernel_source_sha16
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
+        if t.get("_meta", {}).get("kernel_source_sha16") != kernel_source_sha16():
+            return None
         return t[kernel]["hbm_bytes_per_launch"]
     except Exception:
         return None
@@ -254,7 +259,7 @@ def main():
         "metric": "adversarial images/sec (PGD-20, ViT-B/16+LoRA r=8, bs256)",
         "value": value, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"PGD-{args.pgd_steps} eps=8/255 alpha=2/255 random_start, ViT-B/16 (21 classes) + LoRA "
                                f"r={args.rank} on q,k,v,attn-out,fc2 ({'merged' if args.merged else 'fused'}), "
                                f"batch {args.batch}/GPU of synthetic 224x224x3 in HBM, seeded random-init weights",

@@ -279,7 +279,9 @@ def test_attack_after_train_step_uses_the_updated_adapters():
     ref_old = O.pgd(w, cfg, x, y, EPS, ALPHA, steps, lora)
     same_new = ((adv1 - ref_new).abs() < 1e-6).float().mean().item()
     same_old = ((adv1 - ref_old).abs() < 1e-6).float().mean().item()
-    assert same_new > 0.97 and same_old < same_new - 0.02, (same_new, same_old)
+    # (Adam's first step is lr * sign(g): parameters whose gradient is in the fp16 noise move by +-lr either way,
+    #  so the two updated models differ a little more than two models with identical parameters would)
+    assert same_new > 0.92 and same_old < same_new - 0.3, (same_new, same_old)
     assert ((adv0.cpu() - ref_old).abs() < 1e-6).float().mean().item() > 0.97
 
 

@@ -72,3 +72,18 @@ def test_fgsm_is_pgd1_without_random_start(vitb):
     gx, _ = eng.backward(True, False, (64, 3, 224, 224))
     ref = (x[:64] + EPS * torch.sign(gx)).clamp(0, 1)
     assert torch.equal(one, ref)
+
+
+def test_first_attack_of_a_fresh_process_equals_its_replays():
+    """Regression (round 2): in a FRESH process whose first launches happen inside the stream capture, graph replays
+    differed from the first attack until the iteration was run once eagerly before capturing.  Needs its own process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "determinism_probe2.py")], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if "captures" in l]
+    assert len(lines) == 4 and all("equal to first True" in l for l in lines), out.stdout
+    assert all(l.split()[2] == "1" for l in lines), out.stdout          # one capture for four attacks

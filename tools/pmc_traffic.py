@@ -5,10 +5,26 @@ half their bytes -> x2; WRITE_SIZE is exact for 16-byte-per-lane stores.  Counte
 the rocprofv3 derived metric (value * 1024 bytes).
 Usage: python tools/pmc_traffic.py <fetch results.db> <write results.db> <out.json> <out.txt>"""
 import collections
+import hashlib
 import json
+import os
 import re
 import sqlite3
 import sys
+
+
+def kernel_source_sha16():
+    """Fingerprint of the kernel sources the counters were taken on: bench.py reports `traffic` only while the
+    sources still hash to this value (a stale profile is omitted, never quoted)."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                     "adapting-pretrained-vision-transformers-with-lora-against-attack-vectors_amd", "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+
 
 
 def per_kernel(db, counter):
@@ -26,9 +42,9 @@ def per_kernel(db, counter):
     return {k: (acc[k] / len(n[k]), len(n[k])) for k in acc}
 
 
-fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
-write = per_kernel(sys.argv[2], "WRITE_SIZE")
-out, lines = {}, []
+fetch = per_kernel(sys.argv[1], "FETCH_SIZE") if __name__ == "__main__" else {}
+write = per_kernel(sys.argv[2], "WRITE_SIZE") if __name__ == "__main__" else {}
+out, lines = {"_meta": {"kernel_source_sha16": kernel_source_sha16()}}, []
 for k in sorted(fetch, key=lambda k: -(fetch[k][0] * fetch[k][1])):
     f_kb, n = fetch[k]
     w_kb = write.get(k, (0.0, 0))[0]
@@ -37,9 +53,11 @@ for k in sorted(fetch, key=lambda k: -(fetch[k][0] * fetch[k][1])):
               "write_bytes": w_kb * 1024.0, "hbm_bytes_per_launch": tot}
     lines.append(f"{k:40s} launches {n:4d}  FETCH_SIZE {f_kb / 1024:9.1f} MB (x2 gfx950 correction = {2 * f_kb / 1024:9.1f} MB)"
                  f"  WRITE_SIZE {w_kb / 1024:9.1f} MB  -> HBM traffic/launch {tot / 1e6:9.1f} MB")
-json.dump(out, open(sys.argv[3], "w"), indent=1)
-open(sys.argv[4], "w").write(
-    "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 1 --warmup 0 --pgd-steps 2 "
-    "--no-cpu-baseline --no-roofline --no-extras` (batch 256)\nFETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide "
-    "coalesced reads); averages per launch\n\n" + "\n".join(lines) + "\n")
-print("\n".join(lines[:14]))
+if __name__ == "__main__":
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    open(sys.argv[4], "w").write(
+        "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 1 --warmup 0 --pgd-steps 2 "
+        "--no-cpu-baseline --no-roofline --no-extras` (batch 256); kernel sources sha16 " + out["_meta"]["kernel_source_sha16"] +
+        "\nFETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide "
+        "coalesced reads); averages per launch\n\n" + "\n".join(lines) + "\n")
+    print("\n".join(lines[:14]))
