@@ -24,8 +24,10 @@
 #ifdef VITLORA_ATTN_STAMPS   // diagnostic build only (tools/attn_stamp.hip): per-wave s_memtime stamps
 __device__ unsigned long long g_attn_stamps[8192 * 8 * 8];
 #define STAMP(k) do { if (blockIdx.x < 8192 && (threadIdx.x & 63) == 0) g_attn_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ISTAMP(hd, k) do { if ((hd) == 3) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); if (blockIdx.x < 1024 && (threadIdx.x & 63) == 0) g_attn_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = t_; } } while (0)
 #else
 #define STAMP(k) do { } while (0)
+#define ISTAMP(hd, k) do { } while (0)
 #endif
 
 namespace {
@@ -98,6 +100,7 @@ __device__ __forceinline__ h16x8 tr_frag_o(const h16* img, int tile, int st, con
 template <int ROWS, int NW>
 __device__ __forceinline__ void stage_glds(h16* img, const h16* src, int ld, int T, int w, int lane) {
     const int lr = lane >> 3, lc = lane & 7;
+#pragma unroll 1
     for (int g = w; g < ROWS / 8; g += NW) {
         const int r = g * 8 + lr;
         const int rs = r < T ? r : T - 1;
@@ -423,6 +426,463 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const h16* __restrict__
     STAMP(6);
 }
 
+
+// ==========================================================================================
+// Per-IMAGE persistent kernels (large batches: one workgroup per image walks its H heads).
+//   * waves 0 .. NT-1 each own one 32-token block of the image for every head; the last wave is the
+//     LOADER: it streams the next operands into an LDS ring by LDS-DMA while the others compute (the
+//     per-(image, head) kernels above spent half of a workgroup's life in an un-overlapped prologue),
+//     and prepares the per-row constants (backward: LSE and delta = rowsum(dO * O)).
+//   * compute waves issue no LDS-DMA: their own-block fragments come straight from global memory
+//     (requested one phase ahead), so the compiler's own s_waitcnt bookkeeping stays valid for them;
+//     only the loader wave has DMA in flight and it drains it (vmcnt(0)) before every barrier.
+//   * because all heads of an image meet in one workgroup, the LoRA DOWN projections that read the
+//     attention outputs are summed over heads in registers -- t = ctx Ad^T (forward, attention.output.dense)
+//     and u = dqkv Bd^T (backward, query / key / value) -- and the separate skinny GEMM passes over ctx /
+//     dqkv disappear.  The accumulator tile of the previous product is the B operand ("token on the lane").
+// ==========================================================================================
+struct LoraDown {            // rank-r down projection fused into the attention kernels (nullptr W = off)
+    const h16* W;            // forward: Ad [kext, D]; backward: Bd [kext, 3D]   (row j = LoRA column j)
+    h16* out;                // t / u  [B*T (padded), 64]
+    int r;                   // rank (<= 8); backward: q, k, v rows at 0, r, 2r
+    unsigned mods;           // backward: bit 0 / 1 / 2 = query / key / value adapted
+};
+
+// A operand of the down product Y[j][token] = sum_d W[j][d] X[d][token] whose B operand is an accumulator tile X
+// (pack8 of registers 8*st .. 8*st+7): element jj of lane half h must carry k = 16*st + 8*(jj>>2) + 4*h + (jj&3)
+// (the accumulator's row order, see tr_frag32).  The head's slice of W ([8 rows j][64 features], rows >= r zero) was
+// staged in LDS by the loader wave; lanes j >= 8 supply zeros.  dt = feature half of the tile.
+__device__ __forceinline__ h16x8 down_frag_lds(const h16* sW, int dt, int st, int lane) {
+    const int j = lane & 31, h = lane >> 5;
+    h16x4 lo4, hi4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { lo4[k] = (h16)0.f; hi4[k] = (h16)0.f; }
+    if (j < 8) {
+        const h16* p = sW + j * HD + dt * 32 + 16 * st + 4 * h;
+        lo4 = *(const h16x4*)p;
+        hi4 = *(const h16x4*)(p + 8);
+    }
+    return cat4(lo4, hi4);
+}
+// loader wave: rows row0 .. row0 + r - 1 of W (row stride ldw), 64 features from col0 -> sW [8][64], zero rows >= r
+__device__ __forceinline__ void stage_down(h16* sW, const h16* W, int ldw, int row0, int r, int col0, int lane) {
+    const int j = lane >> 3, c8 = (lane & 7) * 8;
+    h16x8 v;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (h16)0.f;
+    if (j < r) v = *(const h16x8*)(W + (size_t)(row0 + j) * ldw + col0 + c8);
+    *(h16x8*)(sW + j * HD + c8) = v;
+}
+// Y (registers 0..3 = rows j = 4h .. 4h+3 of token c) added to the per-token fp32 sums kept in LDS
+__device__ __forceinline__ void down_accumulate(float* acc, const f32x16& y, int tok, int h) {
+    f32x4* p = (f32x4*)(acc + tok * 8 + 4 * h);
+    f32x4 v = *p;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += y[k];
+    *p = v;
+}
+
+constexpr int IMG_WAVES = 8;
+
+template <int NT>
+size_t fwd_img_lds() {
+    return (size_t)4 * NT * 32 * HD * sizeof(h16) + (size_t)(IMG_WAVES - 1) * 2048 + (size_t)NT * 32 * 8 * sizeof(float) +
+           (size_t)2 * 8 * HD * sizeof(h16);
+}
+
+template <int NT>
+__global__ __launch_bounds__(64 * IMG_WAVES) void attn_fwd_img_kernel(const h16* __restrict__ qkv, h16* __restrict__ ctx,
+                                                                      float* __restrict__ lse2, int T, int H, int D,
+                                                                      float scale_log2e, const LoraDown lo) {
+    constexpr int ROWS = NT * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    h16* ring = (h16*)smem;                                   // 4 images: {K, V} of even heads, {K, V} of odd heads
+    char* wimg = smem + (size_t)4 * ROWS * HD * sizeof(h16);  // per-wave output staging (store_rows32_half)
+    float* tsum = (float*)(wimg + (IMG_WAVES - 1) * 2048);    // [ROWS][8] fp32: t summed over heads
+    h16* sAd = (h16*)(tsum + ROWS * 8);                       // [2][8][64]: the head's slice of Ad (head parity)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x;
+    const int ld = 3 * D;
+    const h16* base = qkv + (size_t)b * T * ld;
+    const bool loader = w == IMG_WAVES - 1;
+    const bool active = w < ((T + 31) >> 5);
+    const FragOffs fo = frag_offs(lane);
+    const int tcut = T - 4 * h;
+    const int q = w * 32 + c, qc = q < T ? q : T - 1;
+
+    for (int i = tid; i < ROWS * 8; i += 64 * IMG_WAVES) tsum[i] = 0.f;
+    if (loader) {
+        stage_glds<ROWS, 1>(ring, base + D, ld, T, 0, lane);
+        stage_glds<ROWS, 1>(ring + ROWS * HD, base + 2 * D, ld, T, 0, lane);
+        if (lo.W) {                                            // zero the image's t rows once (columns >= r stay zero)
+            h16x8 z;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) z[k] = (h16)0.f;
+            for (int i = lane; i < T * 8; i += 64) *(h16x8*)(lo.out + ((size_t)b * T + (i >> 3)) * 64 + (i & 7) * 8) = z;
+            stage_down(sAd, lo.W, D, 0, lo.r, 0, lane);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    h16x8 qf[4];
+    if (!loader && active) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const h16x8*)(base + (size_t)qc * ld + 8 * h + 16 * ks);
+    }
+    __syncthreads();
+
+    for (int hd = 0; hd < H; ++hd) {
+        const h16* sK = ring + (hd & 1) * 2 * ROWS * HD;
+        const h16* sV = sK + ROWS * HD;
+        if (loader) {
+            if (hd + 1 < H) {
+                h16* nK = ring + ((hd + 1) & 1) * 2 * ROWS * HD;
+                stage_glds<ROWS, 1>(nK, base + D + (hd + 1) * HD, ld, T, 0, lane);
+                stage_glds<ROWS, 1>(nK + ROWS * HD, base + 2 * D + (hd + 1) * HD, ld, T, 0, lane);
+                if (lo.W) stage_down(sAd + ((hd + 1) & 1) * 8 * HD, lo.W, D, 0, lo.r, (hd + 1) * HD, lane);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (active) {
+            float m = -INFINITY, l = 0.f;
+            f32x16 o[2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+            auto step = [&](int kt, auto masked) {
+                constexpr bool MASKED = decltype(masked)::value;
+                f32x16 s;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) s = mfma32(row_frag_o(sK, kt, fo.row[ks]), qf[ks], s);
+                float tmax = -INFINITY;
+                if constexpr (MASKED) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if ((kt * 32 + (r & 3) + 8 * (r >> 2)) >= tcut) s[r] = -INFINITY;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                if (__any(tmax > m)) {
+                    const float mn = fmaxf(m, tmax);
+                    const float alpha = fexp2((m - mn) * scale_log2e);
+                    m = mn;
+                    l *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                }
+                const float mc = -m * scale_log2e;
+                float ps = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = fexp2(fmaf(s[r], scale_log2e, mc)); ps += s[r]; }
+                l += ps;
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const h16x8 pb = pack8(s, st);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(tr_frag_o(sV, kt, st, fo.tr[dt]), pb, o[dt]);
+                }
+            };
+            const int nfull = T >> 5;
+#pragma unroll 1
+            for (int kt = 0; kt < nfull; ++kt) step(kt, std::false_type{});
+            if (T & 31) step(nfull, std::true_type{});
+            if (hd + 1 < H) {                                  // next head's query fragments fly under the epilogue
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const h16x8*)(base + (size_t)qc * ld + (hd + 1) * HD + 8 * h + 16 * ks);
+            }
+            l += __shfl_xor(l, 32, 64);
+            const float inv = 1.f / l;
+            if (lo.W) {
+                // t^T[j][token] += Ad_h[j][d] * ctx^T[d][token]: the normalised output tile is the B operand
+                f32x16 y;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) y[r] = 0.f;
+                const h16* sA = sAd + (hd & 1) * 8 * HD;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= inv;
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) y = mfma32(down_frag_lds(sA, dt, st, lane), pack8(o[dt], st), y);
+                }
+                down_accumulate(tsum, y, q, h);
+                store_rows32_half(wimg + w * 2048, o, 1.f, ctx + (size_t)b * T * D + hd * HD, D, w * 32, T, lane);
+            } else {
+                store_rows32_half(wimg + w * 2048, o, inv, ctx + (size_t)b * T * D + hd * HD, D, w * 32, T, lane);
+            }
+            if (q < T && h == 0) lse2[((size_t)b * H + hd) * T + q] = m * scale_log2e + log2f(l);
+        }
+        __syncthreads();
+    }
+    if (lo.W && !loader && active && q < T && 4 * h < lo.r) {
+        const f32x4 t4 = *(const f32x4*)(tsum + q * 8 + 4 * h);      // LoRA columns 4h .. 4h+3 of this token
+        h16x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = f2h(t4[k]);
+        *(h16x4*)(lo.out + ((size_t)b * T + q) * 64 + 4 * h) = v;
+    }
+}
+
+template <int NT>
+size_t bwd_img_lds() {
+    return (size_t)4 * NT * 32 * HD * sizeof(h16) + (size_t)2 * NT * 32 * sizeof(float) + (size_t)3 * NT * 32 * 8 * sizeof(float) +
+           (size_t)2 * 3 * 8 * HD * sizeof(h16) + (size_t)(IMG_WAVES - 1) * 2048;
+}
+
+template <int NT>
+__global__ __launch_bounds__(64 * IMG_WAVES) void attn_bwd_img_kernel(const h16* __restrict__ qkv, const h16* __restrict__ ctx,
+                                                                      const h16* __restrict__ dctx, const float* __restrict__ lse2,
+                                                                      h16* __restrict__ dqkv, int T, int H, int D, float scale,
+                                                                      float scale_log2e, const LoraDown lo) {
+    constexpr int ROWS = NT * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    h16* sK = (h16*)smem;                    // slots 0, 1: K, V of the current head (phase A operands)
+    h16* sV = sK + ROWS * HD;
+    h16* sQ = sV + ROWS * HD;                // slots 2, 3: Q, dO of the current head (phase B operands)
+    h16* sdO = sQ + ROWS * HD;
+    float* sLse = (float*)(sdO + ROWS * HD); // [ROWS]  written by the phase A waves, read by phase B
+    float* sDelta = sLse + ROWS;             // [ROWS]
+    float* usum = sDelta + ROWS;             // [3][ROWS][8] fp32: u of query / key / value summed over heads
+    h16* sBd = (h16*)(usum + 3 * ROWS * 8);  // [2][3][8][64]: the head's slices of Bd (head parity; q, k, v)
+    char* wimg = (char*)(sBd + 2 * 3 * 8 * HD);   // per-wave 2 KiB images: results leave as full 128-byte rows
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x;
+    const int ld = 3 * D;
+    const h16* base = qkv + (size_t)b * T * ld;
+    const h16* dobase = dctx + (size_t)b * T * D;
+    const h16* obase = ctx + (size_t)b * T * D;
+    const bool loader = w == IMG_WAVES - 1;
+    const int nb = (T + 31) >> 5;
+    const bool active = w < nb;
+    const FragOffs fo = frag_offs(lane);
+    const int tcut = T - 4 * h;
+    const int tok = w * 32 + c, tokc = tok < T ? tok : T - 1;      // this lane's query (phase A) / key (phase B)
+
+    auto stage_bd = [&](int hd) {            // loader: this head's [8][64] slices of Bd for query / key / value
+        h16* dst = sBd + (hd & 1) * 3 * 8 * HD;
+#pragma unroll
+        for (int md = 0; md < 3; ++md) stage_down(dst + md * 8 * HD, lo.W, ld, md * lo.r, (lo.mods >> md) & 1u ? lo.r : 0, md * D + hd * HD, lane);
+    };
+    for (int i = tid; i < 3 * ROWS * 8; i += 64 * IMG_WAVES) usum[i] = 0.f;
+    if (loader) {
+        stage_glds<ROWS, 1>(sK, base + D, ld, T, 0, lane);
+        stage_glds<ROWS, 1>(sV, base + 2 * D, ld, T, 0, lane);
+        if (lo.W) {
+            h16x8 z;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) z[k] = (h16)0.f;
+            for (int i = lane; i < T * 8; i += 64) *(h16x8*)(lo.out + ((size_t)b * T + (i >> 3)) * 64 + (i & 7) * 8) = z;
+            stage_bd(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    h16x8 fa[4], fb[4], fo_[4];              // own-block fragments: phase A (q, dO rows; O rows for delta), phase B (k, v rows)
+    float lse_own = 0.f;
+    auto fetch_a = [&](int hd) {             // phase A operands of head hd for this lane's query
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            fa[ks] = *(const h16x8*)(base + (size_t)tokc * ld + hd * HD + 8 * h + 16 * ks);
+            fb[ks] = *(const h16x8*)(dobase + (size_t)tokc * D + hd * HD + 8 * h + 16 * ks);
+            fo_[ks] = *(const h16x8*)(obase + (size_t)tokc * D + hd * HD + 8 * h + 16 * ks);
+        }
+        lse_own = lse2[((size_t)b * H + hd) * T + tokc];
+    };
+    if (!loader && active) fetch_a(0);
+    if (w >= 4 && !loader) __builtin_amdgcn_s_setprio(1);     // the second-dispatched half loses VALU arbitration otherwise
+    __syncthreads();
+
+    for (int hd = 0; hd < H; ++hd) {
+        const float* L = sLse;
+        const float* Dl = sDelta;
+        ISTAMP(hd, 0);
+        // ------------------------------ phase A: dQ (query on the lane; K, V images) ------------------------------
+        if (loader) {
+            stage_glds<ROWS, 1>(sQ, base + hd * HD, ld, T, 0, lane);
+            stage_glds<ROWS, 1>(sdO, dobase + hd * HD, D, T, 0, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (active) {
+            // delta = rowsum(dO * O) of the own query from its fragments (each lane half holds 32 of the 64 features);
+            // LSE (rows >= T: +inf -> P = 0) and delta go to LDS for phase B, where every query's constants are needed
+            float delta_q = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) delta_q = fmaf(h2f(fb[ks][k]), h2f(fo_[ks][k]), delta_q);
+            delta_q += __shfl_xor(delta_q, 32, 64);
+            const float lse_q = tok < T ? lse_own : INFINITY;
+            if (tok >= T) delta_q = 0.f;
+            if (h == 0) { sLse[tok] = lse_q; sDelta[tok] = delta_q; }
+            f32x16 dq[2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+            auto stepA = [&](int kt, auto masked) {
+                constexpr bool MASKED = decltype(masked)::value;
+                f32x16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    s = mfma32(row_frag_o(sK, kt, fo.row[ks]), fa[ks], s);                     // S^T[key][q]
+                    dp = mfma32(row_frag_o(sV, kt, fo.row[ks]), fb[ks], dp);                   // dP^T[key][q]
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float p = fexp2(fmaf(s[r], scale_log2e, -lse_q));
+                    if constexpr (MASKED) { if (kt * 32 + (r & 3) + 8 * (r >> 2) >= tcut) p = 0.f; }
+                    dp[r] = p * (dp[r] - delta_q);
+                }
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const h16x8 dsb = pack8(dp, st);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(tr_frag_o(sK, kt, st, fo.tr[dt]), dsb, dq[dt]);
+                }
+            };
+            const int nfull = T >> 5;
+#pragma unroll 1
+            for (int kt = 0; kt < nfull; ++kt) stepA(kt, std::false_type{});
+            if (T & 31) stepA(nfull, std::true_type{});
+            ISTAMP(hd, 1);
+            // phase B fragments of this head: the k, v rows of the own block are still in the K / V images (the loader
+            // overwrites them only after the barrier below)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { fa[ks] = row_frag32(sK, tok, ks, h); fb[ks] = row_frag32(sV, tok, ks, h); }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dq[dt][r] *= scale;
+            if (lo.W && (lo.mods & 1u)) {
+                f32x16 y;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) y[r] = 0.f;
+                const h16* sB = sBd + (hd & 1) * 3 * 8 * HD;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) y = mfma32(down_frag_lds(sB, dt, st, lane), pack8(dq[dt], st), y);
+                down_accumulate(usum, y, tok, h);
+            }
+            // row-per-lane 8-byte stores touch 32 lines per instruction and were a quarter of the head's time here
+            // (tools/attn_img_stamp.hip): the tile leaves through the wave's LDS image as full 128-byte rows
+            store_rows32_half(wimg + w * 2048, dq, 1.f, dqkv + (size_t)b * T * ld + hd * HD, ld, w * 32, T, lane);
+        }
+        ISTAMP(hd, 2);
+        __syncthreads();
+        ISTAMP(hd, 3);
+        // ------------------------------ phase B: dK, dV (key on the lane; Q, dO images) ------------------------------
+        if (loader) {
+            if (hd + 1 < H) {
+                stage_glds<ROWS, 1>(sK, base + D + (hd + 1) * HD, ld, T, 0, lane);
+                stage_glds<ROWS, 1>(sV, base + 2 * D + (hd + 1) * HD, ld, T, 0, lane);
+                if (lo.W) stage_bd(hd + 1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (active) {
+            f32x16 dv[2], dk[2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { dv[dt][r] = 0.f; dk[dt][r] = 0.f; }
+#pragma unroll 1
+            for (int qt = 0; qt < nb; ++qt) {
+                f32x16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    s = mfma32(row_frag_o(sQ, qt, fo.row[ks]), fa[ks], s);                     // S[q][key]
+                    dp = mfma32(row_frag_o(sdO, qt, fo.row[ks]), fb[ks], dp);                  // dP[q][key]
+                }
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const f32x4 lq = *(const f32x4*)(L + qt * 32 + 8 * rq + 4 * h);
+                    const f32x4 dl = *(const f32x4*)(Dl + qt * 32 + 8 * rq + 4 * h);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float p = fexp2(fmaf(s[4 * rq + k], scale_log2e, -lq[k]));   // rows >= T: 0
+                        s[4 * rq + k] = p;
+                        dp[4 * rq + k] = p * (dp[4 * rq + k] - dl[k]);
+                    }
+                }
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const h16x8 pb = pack8(s, st), dsb = pack8(dp, st);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        dv[dt] = mfma32(tr_frag_o(sdO, qt, st, fo.tr[dt]), pb, dv[dt]);        // dV^T[d][key]
+                        dk[dt] = mfma32(tr_frag_o(sQ, qt, st, fo.tr[dt]), dsb, dk[dt]);        // dK^T[d][key]
+                    }
+                }
+            }
+            ISTAMP(hd, 4);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dk[dt][r] *= scale;
+            if (lo.W) {
+                const h16* sB = sBd + (hd & 1) * 3 * 8 * HD;
+#pragma unroll
+                for (int md = 1; md < 3; ++md) {
+                    if (!((lo.mods >> md) & 1u)) continue;
+                    f32x16 y;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) y[r] = 0.f;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                        for (int st = 0; st < 2; ++st)
+                            y = mfma32(down_frag_lds(sB + md * 8 * HD, dt, st, lane), pack8(md == 1 ? dk[dt] : dv[dt], st), y);
+                    down_accumulate(usum + md * ROWS * 8, y, tok, h);
+                }
+            }
+            store_rows32_half(wimg + w * 2048, dk, 1.f, dqkv + (size_t)b * T * ld + D + hd * HD, ld, w * 32, T, lane);
+            store_rows32_half(wimg + w * 2048, dv, 1.f, dqkv + (size_t)b * T * ld + 2 * D + hd * HD, ld, w * 32, T, lane);
+            // next head's phase A operands (q, dO, O rows of the own block, LSE): the registers are free now and the
+            // latency overlaps the wait at the barrier
+            if (hd + 1 < H) fetch_a(hd + 1);
+        }
+        ISTAMP(hd, 5);
+        __syncthreads();
+        ISTAMP(hd, 6);
+    }
+    if (lo.W && !loader && active && tok < T && 4 * h < lo.r) {
+        h16* dst = lo.out + ((size_t)b * T + tok) * 64 + 4 * h;
+#pragma unroll
+        for (int md = 0; md < 3; ++md) {
+            if (!((lo.mods >> md) & 1u)) continue;
+            const f32x4 u4 = *(const f32x4*)(usum + (md * ROWS + tok) * 8 + 4 * h);
+            h16x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = f2h(u4[k]);
+            *(h16x4*)(dst + md * lo.r) = v;
+        }
+    }
+}
+
+template <int NT>
+void launch_fwd_img(const h16* qkv, h16* ctx, float* lse2, int B, int T, int H, int D, const LoraDown& lo, hipStream_t s) {
+    const float sl = 0.125f * 1.4426950408889634f;
+    hipLaunchKernelGGL((attn_fwd_img_kernel<NT>), dim3(B), dim3(64 * IMG_WAVES), fwd_img_lds<NT>(), s, qkv, ctx, lse2, T, H, D, sl, lo);
+}
+template <int NT>
+void launch_bwd_img(const h16* qkv, const h16* ctx, const h16* dctx, const float* lse2, h16* dqkv, int B, int T, int H, int D,
+                    const LoraDown& lo, hipStream_t s) {
+    const float scale = 0.125f;
+    hipLaunchKernelGGL((attn_bwd_img_kernel<NT>), dim3(B), dim3(64 * IMG_WAVES), bwd_img_lds<NT>(), s, qkv, ctx, dctx, lse2, dqkv,
+                       T, H, D, scale, scale * 1.4426950408889634f, lo);
+}
+
 template <int NT>
 size_t bwd_lds() { return (size_t)4 * NT * 32 * HD * sizeof(h16) + (size_t)2 * NT * 32 * sizeof(float); }
 
@@ -444,6 +904,14 @@ int attention32_init(int device) {
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)attn_bwd32_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<7>());
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)attn_fwd_img_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_img_lds<1>());
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)attn_fwd_img_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_img_lds<7>());
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)attn_bwd_img_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_img_lds<1>());
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)attn_bwd_img_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_img_lds<7>());
+    if (e != hipSuccess) return (int)e;
     done[device] = true;
     return 0;
 }
@@ -462,6 +930,32 @@ int k_attention32_bwd(const h16* qkv, const h16* ctx, const h16* dctx, const flo
     ProfScope prof_("attn_bwd32_kernel", 10.0 * B * H * (double)T * T * HD, (double)B * T * D * 16.0, s);
     if (T <= 32) launch_bwd<1>(qkv, ctx, dctx, lse2, dqkv, B, T, H, D, s);
     else if (T <= 224) launch_bwd<7>(qkv, ctx, dctx, lse2, dqkv, B, T, H, D, s);
+    else return -1;
+    return 0;
+}
+
+// Per-image persistent forms (one workgroup per image over all heads) with the LoRA down projection of the
+// consuming linear fused in: W = Ad [64, D] of attention.output.dense (forward, t = ctx Ad^T) or Bd [64, 3D] of the
+// fused q / k / v projection (backward, u = dqkv Bd^T); W == nullptr: attention only.  r <= 8.
+int k_attention_img_fwd(const h16* qkv, h16* ctx, float* lse2, int B, int T, int H, int D, const h16* Ad, h16* t, int r,
+                        hipStream_t s) {
+    ProfScope prof_("attn_fwd_img_kernel", 4.0 * B * H * (double)T * T * HD, (double)B * T * D * 8.0, s);
+    LoraDown lo;
+    lo.W = Ad; lo.out = t; lo.r = r; lo.mods = 1u;
+    if (!Ad || !t || r <= 0 || r > 8) { lo.W = nullptr; lo.out = nullptr; }
+    if (T <= 32) launch_fwd_img<1>(qkv, ctx, lse2, B, T, H, D, lo, s);
+    else if (T <= 224) launch_fwd_img<7>(qkv, ctx, lse2, B, T, H, D, lo, s);
+    else return -1;
+    return 0;
+}
+int k_attention_img_bwd(const h16* qkv, const h16* ctx, const h16* dctx, const float* lse2, h16* dqkv, int B, int T, int H, int D,
+                        const h16* Bd, h16* u, int r, unsigned mods, hipStream_t s) {
+    ProfScope prof_("attn_bwd_img_kernel", 10.0 * B * H * (double)T * T * HD, (double)B * T * D * 16.0, s);
+    LoraDown lo;
+    lo.W = Bd; lo.out = u; lo.r = r; lo.mods = mods;
+    if (!Bd || !u || r <= 0 || r > 8 || !mods) { lo.W = nullptr; lo.out = nullptr; }
+    if (T <= 32) launch_bwd_img<1>(qkv, ctx, dctx, lse2, dqkv, B, T, H, D, lo, s);
+    else if (T <= 224) launch_bwd_img<7>(qkv, ctx, dctx, lse2, dqkv, B, T, H, D, lo, s);
     else return -1;
     return 0;
 }

@@ -54,6 +54,12 @@ int k_attention32_fwd(const h16* qkv, h16* ctx, float* lse2, int B, int T, int H
 int k_attention32_bwd(const h16* qkv, const h16* ctx, const h16* dctx, const float* lse2, h16* dqkv, int B, int T,
                       int H, int D, hipStream_t s);
 
+// per-image persistent forms with the LoRA down projection fused in (attention32.hip); Ad / Bd == nullptr: attention only
+int k_attention_img_fwd(const h16* qkv, h16* ctx, float* lse2, int B, int T, int H, int D, const h16* Ad, h16* t, int r,
+                        hipStream_t s);
+int k_attention_img_bwd(const h16* qkv, const h16* ctx, const h16* dctx, const float* lse2, h16* dqkv, int B, int T, int H,
+                        int D, const h16* Bd, h16* u, int r, unsigned mods, hipStream_t s);
+
 // lora_grad.hip
 // dB[n][j] (+)= sum_m dy[m][n] * t[m][j] ; dA[j][k] (+)= sum_m u[m][j] * x[m][k]  (fp32 outputs)
 // inv_gscale: device pointer to the factor that undoes the fp16 gradient scale (element 0 is used; nullptr = 1)

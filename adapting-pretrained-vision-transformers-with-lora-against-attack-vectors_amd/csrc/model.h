@@ -99,6 +99,8 @@ struct vl_model {
     int use_graph = 1;
     int resid_epi = 0;    // VITLORA_RESID=epilogue: residual add in the o / fc2 GEMM epilogue (fp32 read-modify-write), for A/B runs
     int plan_batch = 0, plan_train = 0;
+    int attn_img_mode = -1;   // VITLORA_ATTN_IMG: 1 / 0 force the per-image attention kernels on / off, -1 = by batch size
+    int num_cus = 256;
     int* err_flag = nullptr;                    // pinned host word written by kernels (bad label, ...), read at API entry
     float mean[3] = {0.485f, 0.456f, 0.406f};   // get_normalization, Utils.py:92-93
     float stdv[3] = {0.229f, 0.224f, 0.225f};

@@ -83,6 +83,17 @@ int fused_down_fwd(const vl_model* m, const Linear& ln) {
 
 
 
+// per-image persistent attention kernels: when the batch fills the chip (one workgroup per image), or forced by
+// VITLORA_ATTN_IMG = 1 / 0 (tests exercise both forms at small batches)
+bool attn_img(const vl_model* m, int B) {
+    if (m->attn_img_mode >= 0) return m->attn_img_mode != 0;
+    return B * 4 >= m->num_cus * 3;
+}
+// LoRA down projection that the per-image attention kernels can sum over heads in registers: rank <= 8, 64-column t / u
+bool down_fusable(const vl_model* m, const Linear& ln) {
+    return !m->cfg.lora_merged && !ln.slots.empty() && ln.kext == 64 && m->r <= 8;
+}
+
 // y = x W^T (+ LoRA) with epilogue; `t` receives the LoRA down projection when fused.
 // stream_id = layer*4 + projection: names the dropout mask of this projection's LoRA branch input.
 // t_ready: the LayerNorm that produced x already wrote t (fused_down_fwd below).
@@ -223,6 +234,8 @@ int vl_create(const vl_config* cfg, vl_model** out) {
     const char* ng = getenv("VITLORA_NO_GRAPH");
     m->use_graph = !(ng && ng[0] == '1');
     { const char* re = getenv("VITLORA_RESID"); m->resid_epi = (re && !strcmp(re, "epilogue")) ? 1 : 0; }
+    { const char* ai = getenv("VITLORA_ATTN_IMG"); m->attn_img_mode = ai ? (ai[0] == '1' ? 1 : 0) : -1; }
+    { hipDeviceProp_t prop; m->num_cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256; }
     const int D = m->D, MLP = m->MLP, r = m->r;
     int rc;
 #define A_(p, n) if ((rc = dev_alloc(m, &(p), (size_t)(n))) != VL_OK) { vl_destroy(m); return rc; }
@@ -578,10 +591,17 @@ static int forward_impl(vl_model* m, const float* x, int B, int normalise, int t
         else k_layernorm_fwd(w.xs[2 * l - 1], w.h1[l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, ly.ln1_b, M, D, m->cfg.ln_eps, delta, w.xs[2 * l], P1, n1, w.t[LQKV][l], s);
         memset(&g, 0, sizeof g); g.C = w.qkv[l]; g.ldc = 3 * D;
         linear_fwd(m, ly.lin[LQKV], w.h1[l], w.t[LQKV][l], Mpad, g, EPI_STORE_H16, s, l * 4 + LQKV, n1 > 0);
-        if (k_attention32_fwd(w.qkv[l], w.ctx[l], w.lse[l], B, T, m->H, D, s)) return fail(VL_ERR_UNSUPPORTED, "attention: T > 224");
+        // large batches: one persistent workgroup per image walks the heads; the LoRA down projection of the output
+        // projection (t = ctx Ad^T) is summed over heads inside it, the skinny GEMM over ctx disappears
+        const bool img = attn_img(m, B);
+        const bool t_o = img && down_fusable(m, ly.lin[LO]) && !vl_drop_on(m);
+        if (img) {
+            if (k_attention_img_fwd(w.qkv[l], w.ctx[l], w.lse[l], B, T, m->H, D, t_o ? ly.lin[LO].Ad : nullptr, w.t[LO][l], m->r, s))
+                return fail(VL_ERR_UNSUPPORTED, "attention: T > 224");
+        } else if (k_attention32_fwd(w.qkv[l], w.ctx[l], w.lse[l], B, T, m->H, D, s)) return fail(VL_ERR_UNSUPPORTED, "attention: T > 224");
         memset(&g, 0, sizeof g); g.C = delta; g.ldc = D;
         if (re) { g.C = w.xs[2 * l + 1]; g.R = w.xs[2 * l]; g.ldr = D; }
-        linear_fwd(m, ly.lin[LO], w.ctx[l], w.t[LO][l], Mpad, g, re ? EPI_RESID_F32 : EPI_STORE_H16, s, l * 4 + LO);
+        linear_fwd(m, ly.lin[LO], w.ctx[l], w.t[LO][l], Mpad, g, re ? EPI_RESID_F32 : EPI_STORE_H16, s, l * 4 + LO, t_o);
         if (re) k_layernorm_fwd(w.xs[2 * l + 1], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D, m->cfg.ln_eps, nullptr, nullptr, nullptr, 0, nullptr, s);
         else k_layernorm_fwd(w.xs[2 * l], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D, m->cfg.ln_eps, delta, w.xs[2 * l + 1], nullptr, 0, nullptr, s);
         memset(&g, 0, sizeof g); g.C = w.a[l]; g.ldc = m->MLP; g.C2 = w.z[l]; g.ldc2 = m->MLP;
@@ -685,10 +705,18 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
         memset(&g, 0, sizeof g); g.C = w.dctx; g.ldc = D;
         linear_dgrad(m, ly.lin[LO], w.dres_h, w.u, Mpad, g, EPI_STORE_H16, s, l * 4 + LO, fo > 0);
         wgrad(ly.lin[LO], w.dres_h, w.ctx[l], w.t[LO][l], w.u, l * 4 + LO);
-        if (k_attention32_bwd(w.qkv[l], w.ctx[l], w.dctx, w.lse[l], w.dqkv, B, T, m->H, D, s))
+        const bool img = attn_img(m, B);
+        const bool u_qkv = img && down_fusable(m, ly.lin[LQKV]);
+        if (img) {
+            unsigned mods = 0;
+            for (const Slot& sl : ly.lin[LQKV].slots) mods |= 1u << sl.target_idx;     // q, k, v = target 0, 1, 2
+            if (k_attention_img_bwd(w.qkv[l], w.ctx[l], w.dctx, w.lse[l], w.dqkv, B, T, m->H, D, u_qkv ? ly.lin[LQKV].Bd : nullptr,
+                                    w.u, m->r, mods, s))
+                return fail(VL_ERR_UNSUPPORTED, "attention: T > 224");
+        } else if (k_attention32_bwd(w.qkv[l], w.ctx[l], w.dctx, w.lse[l], w.dqkv, B, T, m->H, D, s))
             return fail(VL_ERR_UNSUPPORTED, "attention: T > 224");
         memset(&g, 0, sizeof g); g.C = w.dh; g.ldc = D;
-        linear_dgrad(m, ly.lin[LQKV], w.dqkv, w.u, Mpad, g, EPI_STORE_H16, s, l * 4 + LQKV);
+        linear_dgrad(m, ly.lin[LQKV], w.dqkv, w.u, Mpad, g, EPI_STORE_H16, s, l * 4 + LQKV, u_qkv);
         wgrad(ly.lin[LQKV], w.dqkv, w.h1[l], w.t[LQKV][l], w.u, l * 4 + LQKV);
         const int ff = l > 0 ? fused_down(m, m->layers[l - 1].lin[LFC2]) : 0;     // next consumer: fc2 dgrad of the layer below
         k_layernorm_bwd(w.dh, w.xs[2 * l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, w.dres[cur], w.dres[cur ^ 1], w.dres_h,

@@ -308,3 +308,41 @@ def test_adam_and_quantiser():
     assert torch.allclose(p.cpu(), q, rtol=1e-5, atol=1e-7)
     img = torch.rand(2, 3, 17, 19) * 1.2 - 0.1
     assert torch.equal(eng.quantize_u8(img.cuda()).cpu(), O.save_images_quant(img))
+
+
+@pytest.mark.parametrize("prec", ["f16"])
+@pytest.mark.parametrize("image_size,batch", [(64, 5), (224, 3)])
+@pytest.mark.parametrize("r,targets", [(8, ("q", "k", "v", "o", "fc2")), (4, ("q", "v")), (8, ("k", "o")), (0, ())])
+def test_per_image_attention_kernels_with_fused_lora_down(image_size, batch, r, targets, prec, monkeypatch):
+    """The persistent per-image attention kernels (chosen by themselves for chip-filling batches, forced here) sum the
+    LoRA down projections t = ctx Ad^T and u = dqkv Bd^T over heads in registers: same parity bar as the per-head
+    kernels + skinny GEMMs they replace, including the LoRA gradients that read t and u."""
+    monkeypatch.setenv("VITLORA_ATTN_IMG", "1")
+    cfg, w, lora, x, y = make_case(image_size=image_size, batch=batch, r=r, targets=targets)
+    eng = make_engine(cfg, w, lora, precision=prec)
+    xn = O.normalise(x)
+    train = r > 0
+    logits = eng.forward(xn.cuda(), normalise=False, train=train).cpu()
+    eng.loss_ce(y.cuda())
+    gx, gp = eng.backward(True, train, tuple(x.shape))
+    torch.cuda.synchronize()
+    _, g_ref, lg_ref = O.loss_and_input_grad(w, cfg, xn, y, lora, normalised=True)
+    assert rel_l2(logits, lg_ref) < TOL_ACT[prec]
+    assert rel_l2(gx.cpu(), g_ref) < TOL_GRAD[prec]
+    if train:
+        _, _, grads = O.lora_train_grads(w, cfg, xn, y, lora)
+        base = eng.flat.data_ptr()
+        for i in range(cfg.layers):
+            for t in lora.targets:
+                for which in ("A", "B"):
+                    v = eng.param(i, t, which)
+                    off = (v.data_ptr() - base) // 4
+                    got = gp[off:off + v.numel()].view(v.shape).cpu()
+                    assert rel_l2(got, grads[(which, i, t)]) < TOL_GRAD[prec], (i, t, which)
+    # same engine configuration through the per-head kernels: the two forms agree far below the parity bar
+    monkeypatch.setenv("VITLORA_ATTN_IMG", "0")
+    eng2 = make_engine(cfg, w, lora, precision=prec)
+    logits2 = eng2.forward(xn.cuda(), normalise=False, train=train).cpu()
+    eng2.loss_ce(y.cuda())
+    gx2, _ = eng2.backward(True, False, tuple(x.shape))
+    assert rel_l2(logits, logits2) < 5e-4 and rel_l2(gx.cpu(), gx2.cpu()) < 1e-3
