@@ -60,6 +60,12 @@ int k_attention_img_fwd(const h16* qkv, h16* ctx, float* lse2, int B, int T, int
 int k_attention_img_bwd(const h16* qkv, const h16* ctx, const h16* dctx, const float* lse2, h16* dqkv, int B, int T, int H,
                         int D, const h16* Bd, h16* u, int r, unsigned mods, hipStream_t s);
 
+// patch.hip: adversarial-patch overlay (warp-and-paste) and its gradient w.r.t. the patch
+void k_patch_overlay(const float* img, const float* patch, const float* mats, float* out, int B, int S, int ps, int circle,
+                     hipStream_t s);
+void k_patch_overlay_bwd(const float* g, const float* mats, float* dpatch, int B, int S, int ps, int circle, hipStream_t s);
+void k_clamp(float* x, float lo, float hi, int64_t n, hipStream_t s);
+
 // lora_grad.hip
 // dB[n][j] (+)= sum_m dy[m][n] * t[m][j] ; dA[j][k] (+)= sum_m u[m][j] * x[m][k]  (fp32 outputs)
 // inv_gscale: device pointer to the factor that undoes the fp16 gradient scale (element 0 is used; nullptr = 1)

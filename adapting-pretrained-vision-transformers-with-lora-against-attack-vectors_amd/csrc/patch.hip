@@ -1,0 +1,180 @@
+// Adversarial-patch overlay (expectation over transformations) -- the differentiable warp-and-paste step that the
+// reference reaches through ART's AdversarialPatchPyTorch._random_overlay (patch_attack.py:47-75, 193-208):
+//
+//     padded_patch = resize(patch  -> S x S, bilinear)            mask = resize(circle / square mask -> S x S, bilinear)
+//     per image:  P' = affine(padded_patch, angle, translate, scale; bilinear, zero fill)
+//                 M' = affine(mask,         angle, translate, scale; nearest,  zero fill)
+//     out = clamp(image * (1 - M') + P' * M', 0, 1)
+//
+// restated from ART 1.20.1 / torchvision's tensor affine (grid_sample, align_corners = False); neither package is
+// installable here, so the oracle (oracle/patch_oracle.py) is a torch restatement of the same formulas and these
+// kernels are held to it ("parity unpinned").  The host passes the INVERSE affine matrix per image (6 floats,
+// torchvision's _get_inverse_affine_matrix, computed in double); both kernels are HBM-bound elementwise passes.
+#include "kernels.h"
+#include "prof.h"
+
+namespace {
+
+struct Tap { int i0, i1; float w0, w1; };
+
+// torch bilinear resize in -> out (align_corners = False): source position of destination index d
+__device__ __forceinline__ Tap resize_tap(int d, int in, float ratio) {
+    float src = ((float)d + 0.5f) * ratio - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    int i0 = (int)src;
+    i0 = i0 > in - 1 ? in - 1 : i0;
+    const int i1 = i0 + 1 < in ? i0 + 1 : in - 1;
+    const float l = src - (float)i0;
+    return {i0, i1, 1.f - l, l};
+}
+
+// ART's circular mask on a ps x ps grid: 1 - clip((x^2 + y^2)^40, -1, 1), x, y = linspace(-1, 1, ps); square: ones
+__device__ __forceinline__ float base_mask(int r, int c, int ps, int circle) {
+    if (!circle) return 1.f;
+    const float x = ps > 1 ? -1.f + 2.f * c / (float)(ps - 1) : 0.f;
+    const float y = ps > 1 ? -1.f + 2.f * r / (float)(ps - 1) : 0.f;
+    const float z = powf(x * x + y * y, 40.f);
+    return 1.f - fminf(fmaxf(z, -1.f), 1.f);
+}
+
+// resized mask at integer position (i, j) of the S x S canvas
+__device__ __forceinline__ float mask_at(int j, int i, int ps, int S, int circle) {
+    if (!circle) return 1.f;
+    const float ratio = (float)ps / (float)S;
+    const Tap ty = resize_tap(j, ps, ratio), tx = resize_tap(i, ps, ratio);
+    return ty.w0 * (tx.w0 * base_mask(ty.i0, tx.i0, ps, 1) + tx.w1 * base_mask(ty.i0, tx.i1, ps, 1)) +
+           ty.w1 * (tx.w0 * base_mask(ty.i1, tx.i0, ps, 1) + tx.w1 * base_mask(ty.i1, tx.i1, ps, 1));
+}
+
+struct Warp {          // per output pixel: source position in the S x S canvas
+    float u, v;        // continuous source pixel coordinates
+};
+__device__ __forceinline__ Warp warp_of(const float* m, int x, int y, int S) {
+    const float xb = (float)x - 0.5f * S + 0.5f, yb = (float)y - 0.5f * S + 0.5f;
+    return {m[0] * xb + m[1] * yb + m[2] + 0.5f * S - 0.5f, m[3] * xb + m[4] * yb + m[5] + 0.5f * S - 0.5f};
+}
+
+__global__ __launch_bounds__(256) void patch_overlay_kernel(const float* __restrict__ img, const float* __restrict__ patch,
+                                                            const float* __restrict__ mats, float* __restrict__ out, int B,
+                                                            int S, int ps, int circle) {
+    const int64_t total = (int64_t)B * S * S;
+    const float ratio = (float)ps / (float)S;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(t % S);
+        const int y = (int)((t / S) % S);
+        const int b = (int)(t / ((int64_t)S * S));
+        const float* m = mats + b * 6;
+        const Warp wp = warp_of(m, x, y, S);
+        // mask: nearest neighbour (round half to even, as grid_sample's nearbyint), zero outside the canvas
+        const int nu = (int)nearbyintf(wp.u), nv = (int)nearbyintf(wp.v);
+        float mk = 0.f;
+        if (nu >= 0 && nu < S && nv >= 0 && nv < S) mk = mask_at(nv, nu, ps, S, circle);
+        float pv[3] = {0.f, 0.f, 0.f};
+        if (mk != 0.f) {
+            // patch: bilinear over the resized canvas, each canvas pixel itself bilinear over the ps x ps patch
+            const float fu = floorf(wp.u), fv = floorf(wp.v);
+            const int u0 = (int)fu, v0 = (int)fv;
+            const float au = wp.u - fu, av = wp.v - fv;
+#pragma unroll
+            for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+                for (int du = 0; du < 2; ++du) {
+                    const int cu = u0 + du, cv = v0 + dv;
+                    if (cu < 0 || cu >= S || cv < 0 || cv >= S) continue;
+                    const float wa = (du ? au : 1.f - au) * (dv ? av : 1.f - av);
+                    const Tap ty = resize_tap(cv, ps, ratio), tx = resize_tap(cu, ps, ratio);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float* pc = patch + c * ps * ps;
+                        pv[c] += wa * (ty.w0 * (tx.w0 * pc[ty.i0 * ps + tx.i0] + tx.w1 * pc[ty.i0 * ps + tx.i1]) +
+                                       ty.w1 * (tx.w0 * pc[ty.i1 * ps + tx.i0] + tx.w1 * pc[ty.i1 * ps + tx.i1]));
+                    }
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int64_t idx = (((int64_t)b * 3 + c) * S + y) * S + x;
+            const float v = img[idx] * (1.f - mk) + pv[c] * mk;
+            out[idx] = fminf(fmaxf(v, 0.f), 1.f);
+        }
+    }
+}
+
+// d(patch)[c][r][s] += sum over pixels g[b][c][y][x] * M' * (affine bilinear weight) * (resize bilinear weight).
+// One workgroup per (image, band of rows): sums in an LDS copy of the patch gradient, then one global atomic per entry.
+__global__ __launch_bounds__(256) void patch_overlay_bwd_kernel(const float* __restrict__ g, const float* __restrict__ mats,
+                                                                float* __restrict__ dpatch, int S, int ps, int circle,
+                                                                int bands) {
+    extern __shared__ float acc[];        // [3][ps][ps]
+    const int n = 3 * ps * ps;
+    for (int i = threadIdx.x; i < n; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    const int b = blockIdx.x / bands, band = blockIdx.x - b * bands;
+    const int rows = (S + bands - 1) / bands;
+    const int y0 = band * rows, y1 = min(S, y0 + rows);
+    const float* m = mats + b * 6;
+    const float ratio = (float)ps / (float)S;
+    for (int t = y0 * S + threadIdx.x; t < y1 * S; t += 256) {
+        const int x = t % S, y = t / S;
+        const Warp wp = warp_of(m, x, y, S);
+        const int nu = (int)nearbyintf(wp.u), nv = (int)nearbyintf(wp.v);
+        if (nu < 0 || nu >= S || nv < 0 || nv >= S) continue;
+        const float mk = mask_at(nv, nu, ps, S, circle);
+        if (mk == 0.f) continue;
+        float gv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gv[c] = g[(((int64_t)b * 3 + c) * S + y) * S + x] * mk;
+        const float fu = floorf(wp.u), fv = floorf(wp.v);
+        const int u0 = (int)fu, v0 = (int)fv;
+        const float au = wp.u - fu, av = wp.v - fv;
+#pragma unroll
+        for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+            for (int du = 0; du < 2; ++du) {
+                const int cu = u0 + du, cv = v0 + dv;
+                if (cu < 0 || cu >= S || cv < 0 || cv >= S) continue;
+                const float wa = (du ? au : 1.f - au) * (dv ? av : 1.f - av);
+                const Tap ty = resize_tap(cv, ps, ratio), tx = resize_tap(cu, ps, ratio);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float* pc = acc + c * ps * ps;
+                    const float gw = gv[c] * wa;
+                    atomicAdd(pc + ty.i0 * ps + tx.i0, gw * ty.w0 * tx.w0);
+                    atomicAdd(pc + ty.i0 * ps + tx.i1, gw * ty.w0 * tx.w1);
+                    atomicAdd(pc + ty.i1 * ps + tx.i0, gw * ty.w1 * tx.w0);
+                    atomicAdd(pc + ty.i1 * ps + tx.i1, gw * ty.w1 * tx.w1);
+                }
+            }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256)
+        if (acc[i] != 0.f) atomicAdd(dpatch + i, acc[i]);
+}
+
+__global__ void clamp_kernel(float* __restrict__ x, float lo, float hi, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) x[i] = fminf(fmaxf(x[i], lo), hi);
+}
+
+}  // namespace
+
+void k_patch_overlay(const float* img, const float* patch, const float* mats, float* out, int B, int S, int ps, int circle,
+                     hipStream_t s) {
+    ProfScope prof_("patch_overlay_kernel", 0.0, (double)B * 3 * S * S * 8.0, s);
+    const int64_t total = (int64_t)B * S * S;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(patch_overlay_kernel, dim3((unsigned)blocks), dim3(256), 0, s, img, patch, mats, out, B, S, ps, circle);
+}
+void k_patch_overlay_bwd(const float* g, const float* mats, float* dpatch, int B, int S, int ps, int circle, hipStream_t s) {
+    ProfScope prof_("patch_overlay_bwd_kernel", 0.0, (double)B * 3 * S * S * 4.0, s);
+    (void)hipMemsetAsync(dpatch, 0, (size_t)3 * ps * ps * sizeof(float), s);
+    const int bands = 8;
+    hipLaunchKernelGGL(patch_overlay_bwd_kernel, dim3(B * bands), dim3(256), (size_t)3 * ps * ps * sizeof(float), s, g, mats,
+                       dpatch, S, ps, circle, bands);
+}
+void k_clamp(float* x, float lo, float hi, int64_t n, hipStream_t s) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(clamp_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, s, x, lo, hi, n);
+}

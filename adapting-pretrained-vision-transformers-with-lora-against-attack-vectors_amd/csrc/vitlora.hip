@@ -902,6 +902,35 @@ int vl_quantize_u8(const float* images, uint8_t* out_hwc, int batch, int channel
     return VL_OK;
 }
 
+// ---- adversarial patch (patch_attack.py: ART AdversarialPatchPyTorch) ------------------------------------
+int vl_patch_apply(const float* images, const float* patch, const float* inv_affine, int batch, int image_size, int patch_size,
+                   int patch_type, float* out, void* stream) {
+    if (!images || !patch || !inv_affine || !out || out == images) return fail(VL_ERR_ARG, "bad argument");
+    if (batch <= 0 || image_size <= 0 || patch_size <= 0 || patch_size > 64 || patch_size > image_size)
+        return fail(VL_ERR_UNSUPPORTED, "patch_size must be in [1, min(64, image_size)]");
+    if (patch_type != 0 && patch_type != 1) return fail(VL_ERR_ARG, "patch_type: 0 = square, 1 = circle");
+    k_patch_overlay(images, patch, inv_affine, out, batch, image_size, patch_size, patch_type, (hipStream_t)stream);
+    if (!capturing((hipStream_t)stream)) return check_launch("vl_patch_apply");
+    return VL_OK;
+}
+
+int vl_patch_grad(const float* grad_out, const float* inv_affine, int batch, int image_size, int patch_size, int patch_type,
+                  float* patch_grad, void* stream) {
+    if (!grad_out || !inv_affine || !patch_grad) return fail(VL_ERR_ARG, "bad argument");
+    if (batch <= 0 || image_size <= 0 || patch_size <= 0 || patch_size > 64 || patch_size > image_size)
+        return fail(VL_ERR_UNSUPPORTED, "patch_size must be in [1, min(64, image_size)]");
+    if (patch_type != 0 && patch_type != 1) return fail(VL_ERR_ARG, "patch_type: 0 = square, 1 = circle");
+    k_patch_overlay_bwd(grad_out, inv_affine, patch_grad, batch, image_size, patch_size, patch_type, (hipStream_t)stream);
+    if (!capturing((hipStream_t)stream)) return check_launch("vl_patch_grad");
+    return VL_OK;
+}
+
+int vl_clamp(float* x, float lo, float hi, int64_t n, void* stream) {
+    if (!x || n <= 0 || !(lo <= hi)) return fail(VL_ERR_ARG, "bad argument");
+    k_clamp(x, lo, hi, n, (hipStream_t)stream);
+    return VL_OK;
+}
+
 // ---- GEMM micro-benchmark (tools/gemm_sweep.py): random h16 operands, HIP-event timing -----
 int vl_bench_gemm(int M, int N, int K1, int K2, int epi, int bn, int iters, float* ms_out) {
     if (M % 128 || N % 64 || K1 % 64 || K2 % 64 || iters <= 0 || !ms_out) return fail(VL_ERR_ARG, "bad argument");

@@ -290,6 +290,30 @@ class Engine:
                                     C.c_void_p(m2.data_ptr()), float(lr), float(b1), float(b2), float(eps), int(t),
                                     param.numel(), self._stream()), "vl_adam_step")
 
+    # -- adversarial patch (patch_attack.py) ---------------------------------------------------------
+    def patch_apply(self, images: torch.Tensor, patch: torch.Tensor, inv_affine: torch.Tensor, patch_type: int,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        images = self._check_images(images)
+        patch = self._f32(patch)
+        mats = self._f32(inv_affine)
+        out = torch.empty_like(images) if out is None else out
+        check(self.lib.vl_patch_apply(C.c_void_p(images.data_ptr()), C.c_void_p(patch.data_ptr()), C.c_void_p(mats.data_ptr()),
+                                      images.shape[0], images.shape[2], patch.shape[-1], int(patch_type),
+                                      C.c_void_p(out.data_ptr()), self._stream()), "vl_patch_apply")
+        return out
+
+    def patch_grad(self, grad_out: torch.Tensor, inv_affine: torch.Tensor, patch_size: int, patch_type: int) -> torch.Tensor:
+        g = self._f32(grad_out)
+        mats = self._f32(inv_affine)
+        dp = torch.empty(3, patch_size, patch_size, dtype=torch.float32, device=self.device)
+        check(self.lib.vl_patch_grad(C.c_void_p(g.data_ptr()), C.c_void_p(mats.data_ptr()), g.shape[0], g.shape[2],
+                                     int(patch_size), int(patch_type), C.c_void_p(dp.data_ptr()), self._stream()), "vl_patch_grad")
+        return dp
+
+    def clamp_(self, x: torch.Tensor, lo: float, hi: float):
+        check(self.lib.vl_clamp(C.c_void_p(x.data_ptr()), float(lo), float(hi), x.numel(), self._stream()), "vl_clamp")
+        return x
+
     def set_dropout_seed(self, seed: int):
         check(self.lib.vl_set_dropout_seed(self.h, int(seed)), "vl_set_dropout_seed")
 

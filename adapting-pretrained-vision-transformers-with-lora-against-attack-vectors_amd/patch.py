@@ -1,0 +1,171 @@
+"""Adversarial-patch attack with expectation over transformations on the HIP engine -- the part of ART's
+`AdversarialPatchPyTorch` that the reference uses (patch_attack.py:47-75 constructor arguments, :193-194 `generate`,
+:199-208 `apply_patch`), same argument names.
+
+Per optimiser step, all on the device: the host samples one (scale, rotation, shift) per image and builds the inverse
+affine matrices; `vl_patch_apply` warps and pastes the patch; `vl_forward` / `vl_loss_ce` / `vl_backward_input` give
+d(CE)/d(pixels); `vl_patch_grad` pulls it back onto the patch; with a process group the [3, ps, ps] gradient is summed
+over ranks (12 KB all-reduce); `vl_adam_step` + `vl_clamp` update the patch.
+
+ART and torchvision are not installable here: the algorithm is restated from their published sources and checked
+against oracle/patch_oracle.py ("parity unpinned").
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+
+def inverse_affine_matrix(angle_deg: float, translate: Tuple[float, float], scale: float):
+    """torchvision `_get_inverse_affine_matrix` for centre = image centre, shear 0 (what `affine(img, angle, translate,
+    scale, shear=[0, 0])` uses): maps output pixel offsets from the centre to input offsets."""
+    rot = math.radians(angle_deg)
+    cs, sn = math.cos(rot), math.sin(rot)
+    tx, ty = translate
+    m = [cs / scale, sn / scale, 0.0, -sn / scale, cs / scale, 0.0]
+    m[2] = m[0] * (-tx) + m[1] * (-ty)
+    m[5] = m[3] * (-tx) + m[4] * (-ty)
+    return m
+
+
+class AdversarialPatchPyTorch:
+    """Drop-in for the calls patch_attack.py makes.  `estimator` is a vitlora model (optionally wrapped in LogitsModel /
+    NormalizedModel / PeftModel); images are [0, 1] NCHW, the model is fed (x - mean) / std inside the patch gather."""
+
+    def __init__(self, estimator, rotation_max: float = 22.5, scale_min: float = 0.1, scale_max: float = 1.0,
+                 distortion_scale_max: float = 0.0, learning_rate: float = 5.0, max_iter: int = 500, batch_size: int = 16,
+                 patch_shape: Sequence[int] = (3, 224, 224), patch_location: Optional[Tuple[int, int]] = None,
+                 patch_type: str = "circle", optimizer: str = "Adam", targeted: bool = True, verbose: bool = True,
+                 seed: int = 0, mean=None, std=None, process_group=None):
+        from .attacks import _unwrap
+        from .engine import IMAGENET_MEAN, IMAGENET_STD
+        if distortion_scale_max != 0.0:
+            raise NotImplementedError("perspective distortion (distortion_scale_max > 0) is not on the accelerated path; "
+                                      "the reference runs with 0.0 (patch_attack.py:98)")
+        if patch_type not in ("circle", "square"):
+            raise ValueError("patch_type must be 'circle' or 'square'")
+        if optimizer not in ("Adam", "pgd"):
+            raise ValueError("optimizer must be 'Adam' or 'pgd'")
+        if len(patch_shape) != 3 or patch_shape[0] != 3 or patch_shape[1] != patch_shape[2]:
+            raise ValueError("patch_shape must be (3, ps, ps)")
+        self.vit = _unwrap(estimator)
+        self.eng = self.vit._engine()
+        self.rotation_max, self.scale_min, self.scale_max = float(rotation_max), float(scale_min), float(scale_max)
+        self.learning_rate, self.max_iter, self.batch_size = float(learning_rate), int(max_iter), int(batch_size)
+        self.patch_shape, self.patch_location = tuple(patch_shape), patch_location
+        self.patch_type, self.optimizer, self.targeted, self.verbose = patch_type, optimizer, bool(targeted), verbose
+        self.mean, self.std = list(mean or IMAGENET_MEAN), list(std or IMAGENET_STD)
+        self.group = process_group
+        self._gen = torch.Generator().manual_seed(int(seed))
+        ps = patch_shape[1]
+        # ART: the patch starts at the middle of the classifier's clip_values = (0, 1)
+        self._patch = torch.full((3, ps, ps), 0.5, dtype=torch.float32, device=self.eng.device)
+        self._m1 = torch.zeros_like(self._patch)
+        self._m2 = torch.zeros_like(self._patch)
+        self._t = 0
+        self.last_params = None
+
+    # -- sampling (host) --------------------------------------------------------------------------------------
+    def sample_params(self, n: int, scale: Optional[float] = None):
+        """ART `_random_overlay`: scale ~ U(scale_min, scale_max) unless given; shifts ~ U(-pad, pad), pad = (S - scale*S)/2
+        (or fixed by patch_location); rotation ~ U(-rotation_max, rotation_max)."""
+        S = self.vit.arch.image_size
+        ps = self.patch_shape[1]
+        out = []
+        for _ in range(n):
+            u = torch.rand(4, generator=self._gen, dtype=torch.float64).tolist()
+            sc = float(scale) if scale is not None else self.scale_min + (self.scale_max - self.scale_min) * u[0]
+            if self.patch_location is None:
+                pad = (S - sc * S) / 2.0
+                tx, ty = (2 * u[2] - 1) * pad, (2 * u[3] - 1) * pad
+            else:
+                pad = int(math.floor(S - ps) / 2.0)
+                tx, ty = -pad + self.patch_location[0], -pad + self.patch_location[1]
+            out.append((sc, (2 * u[1] - 1) * self.rotation_max, tx, ty))
+        return out
+
+    def _matrices(self, params) -> torch.Tensor:
+        m = [inverse_affine_matrix(ang, (tx, ty), sc) for sc, ang, tx, ty in params]
+        return torch.tensor(m, dtype=torch.float32, device=self.eng.device)
+
+    # -- one optimiser step -----------------------------------------------------------------------------------
+    def train_step(self, images: torch.Tensor, labels: torch.Tensor, params=None) -> torch.Tensor:
+        """ART `_train_step`: returns the CE of the patched batch before the update."""
+        eng = self.eng
+        images = images.to(device=eng.device, dtype=torch.float32).contiguous()
+        labels = labels.to(device=eng.device, dtype=torch.int64).contiguous()
+        params = params if params is not None else self.sample_params(images.shape[0])
+        self.last_params = params
+        mats = self._matrices(params)
+        ptype = 1 if self.patch_type == "circle" else 0
+        eng.set_normalization(self.mean, self.std)
+        patched = eng.patch_apply(images, self._patch, mats, ptype)
+        eng.forward(patched, normalise=True, train=False)
+        ce = eng.loss_ce(labels)
+        gx, _ = eng.backward(True, False, tuple(images.shape))
+        g = eng.patch_grad(gx, mats, self.patch_shape[1], ptype)          # d CE / d patch
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(g, group=self.group)                          # 12 KB at ps = 32
+            g /= dist.get_world_size(self.group)
+        # ART minimises loss = -CE (untargeted, Adam) or +CE (targeted); "pgd": patch += / -= lr * sign(grad)
+        ascent = not self.targeted
+        if self.optimizer == "pgd":
+            self._patch.add_(torch.sign(g), alpha=self.learning_rate if ascent else -self.learning_rate)
+        else:
+            self._t += 1
+            flat, gf = self._patch.view(-1), (-g if ascent else g).reshape(-1).contiguous()
+            eng.adam_step(flat, gf, self._m1.view(-1), self._m2.view(-1), self.learning_rate, 0.9, 0.999, 1e-8, self._t)
+        eng.clamp_(self._patch, 0.0, 1.0)
+        return ce
+
+    def generate(self, x, y, **kwargs):
+        """`attack.generate(x=x_train, y=y_train)` (patch_attack.py:194): max_iter passes over the data in batches."""
+        x = torch.as_tensor(x)
+        y = torch.as_tensor(y)
+        if y.dim() == 2:
+            y = y.argmax(1)
+        for it in range(self.max_iter):
+            order = torch.randperm(x.shape[0], generator=self._gen)           # ART's DataLoader(shuffle=True)
+            for s0 in range(0, x.shape[0], self.batch_size):
+                idx = order[s0:s0 + self.batch_size]
+                ce = self.train_step(x[idx], y[idx])
+            if self.verbose and (it % 50 == 0 or it == self.max_iter - 1):
+                print(f"  patch iter {it + 1}/{self.max_iter}: CE {float(ce):.4f}")
+        mask = self.patch_mask()
+        return self._patch.detach().cpu().numpy(), mask.numpy()
+
+    def patch_mask(self) -> torch.Tensor:
+        ps = self.patch_shape[1]
+        if self.patch_type == "square":
+            return torch.ones(3, ps, ps)
+        lin = torch.linspace(-1, 1, ps)
+        xg, yg = torch.meshgrid(lin, lin, indexing="ij")
+        return (1 - torch.clamp((xg ** 2 + yg ** 2) ** 40, -1, 1)).expand(3, ps, ps).clone()
+
+    def apply_patch(self, x, scale: float, patch_external=None, params=None):
+        """`attack.apply_patch(images_np, scale=scale)` (patch_attack.py:204): random rotation / location, given scale."""
+        xt = torch.as_tensor(x).to(device=self.eng.device, dtype=torch.float32).contiguous()
+        patch = self._patch if patch_external is None else torch.as_tensor(patch_external).to(self.eng.device).float()
+        params = params if params is not None else self.sample_params(xt.shape[0], scale=scale)
+        self.last_params = params
+        out = self.eng.patch_apply(xt, patch, self._matrices(params), 1 if self.patch_type == "circle" else 0)
+        return out.cpu().numpy() if not isinstance(x, torch.Tensor) else out
+
+
+class NormalizedModel(torch.nn.Module):
+    """patch_attack.py:16-25: feeds (x - mean) / std to the wrapped model."""
+
+    def __init__(self, model, mean, std):
+        super().__init__()
+        self.mean = torch.tensor(mean).view(1, 3, 1, 1)
+        self.std = torch.tensor(std).view(1, 3, 1, 1)
+        self.model = model
+
+    def forward(self, x):
+        return self.model((x - self.mean.to(x.device)) / self.std.to(x.device))
+
+
+__all__ = ["AdversarialPatchPyTorch", "NormalizedModel", "inverse_affine_matrix"]

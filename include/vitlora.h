@@ -182,6 +182,20 @@ int vl_quantize_u8(const float* images, uint8_t* out_hwc, int batch, int channel
 int vl_channel_affine(float* dst, const float* src, const float scale[3], const float shift[3],
                       int batch, int64_t hw, void* stream);
 
+/* Adversarial patch with expectation over transformations: the overlay ART's AdversarialPatchPyTorch._random_overlay
+ * computes for patch_attack.py:47-75,193-208 (generate / apply_patch).  patch [3,ps,ps] fp32 in [0,1]; inv_affine [B,6]
+ * fp32 device = per-image INVERSE affine matrix of torchvision's affine(angle, translate, scale) (the host samples scale /
+ * rotation / location and builds it: patch.py); patch_type 0 = square, 1 = circle.  out may not alias images.
+ *   out = clamp(images * (1 - M') + P' * M', 0, 1),  P' / M' = the resized (bilinear, ps -> S) patch / mask warped by the affine
+ *   (bilinear / nearest, zero fill).
+ * vl_patch_grad: d(loss)/d(patch) [3,ps,ps] from d(loss)/d(out) of the same overlay (the input gradient of vl_backward_input). */
+int vl_patch_apply(const float* images, const float* patch, const float* inv_affine, int batch, int image_size,
+                   int patch_size, int patch_type, float* out, void* stream);
+int vl_patch_grad(const float* grad_out, const float* inv_affine, int batch, int image_size, int patch_size, int patch_type,
+                  float* patch_grad, void* stream);
+/* x <- clamp(x, lo, hi): the patch is clipped to the classifier's clip_values after every optimiser step. */
+int vl_clamp(float* x, float lo, float hi, int64_t n, void* stream);
+
 /* Per-launch timing with HIP events on the launch stream, for bench.py's roofline object.
  * Between begin and report every kernel launch of this library is bracketed by an event
  * pair (PGD runs eagerly, not as a graph, while active).  report synchronises the device and

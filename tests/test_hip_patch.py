@@ -1,0 +1,132 @@
+"""Adversarial-patch EoT path (BASELINE config 5; reference: patch_attack.py through ART's AdversarialPatchPyTorch).
+PARITY UNPINNED: ART / torchvision are not installable, the oracle (oracle/patch_oracle.py) restates their published
+algorithms; these tests hold the HIP kernels and the composed train step to that restatement."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import O, PKG, make_case, make_engine, pkg, rel_l2
+from oracle import patch_oracle as PO
+
+pytestmark = pytest.mark.gpu
+
+PARAMS = [(1.0, 0.0, 0.0, 0.0), (0.5, 10.0, 3.0, -2.0), (0.23, -22.5, -17.3, 9.9), (0.05, 3.0, 40.0, 40.0), (0.8, 17.0, 5.5, -6.25)]
+
+
+def _mats(P, params):
+    patch_mod = importlib.import_module(PKG + ".patch")
+    return torch.tensor([patch_mod.inverse_affine_matrix(a, (tx, ty), s) for s, a, tx, ty in params], dtype=torch.float32)
+
+
+@pytest.mark.parametrize("S,ps", [(64, 16), (224, 32), (224, 24)])
+@pytest.mark.parametrize("ptype", ["square", "circle"])
+def test_overlay_and_patch_gradient_match_oracle(S, ps, ptype):
+    P = pkg()
+    cfg, w, _, _, _ = make_case(batch=1, r=0)
+    eng = make_engine(cfg, w)
+    g = torch.Generator().manual_seed(S + ps)
+    B = len(PARAMS)
+    img = torch.rand(B, 3, S, S, generator=g)
+    patch = torch.rand(3, ps, ps, generator=g)
+    mats = _mats(P, PARAMS)
+    # host matrices == the oracle's restatement of torchvision's _get_inverse_affine_matrix
+    for (s, a, tx, ty), m in zip(PARAMS, mats.tolist()):
+        assert np.allclose(m, PO.inverse_affine_matrix(a, (tx, ty), s), atol=1e-6)
+    ptype_i = 1 if ptype == "circle" else 0
+    eng._check_images = lambda t: eng._f32(t)                      # sizes other than the engine's image size
+    out = eng.patch_apply(img.cuda(), patch.cuda(), mats.cuda(), ptype_i).cpu()
+    ref = PO.overlay(img, patch, ptype, PARAMS)
+    diff = (out - ref).abs()
+    # nearest-neighbour mask: a source coordinate that lands within float rounding of x.5 may pick the other pixel
+    assert (diff > 1e-4).float().mean().item() < 2e-4, (diff > 1e-4).float().mean().item()
+    assert diff.median().item() < 1e-6
+    # gradient w.r.t. the patch for a random upstream gradient
+    gout = torch.randn(B, 3, S, S, generator=g)
+    p = patch.clone().requires_grad_(True)
+    (PO.overlay(img, p, ptype, PARAMS) * gout).sum().backward()
+    dp = eng.patch_grad(gout.cuda(), mats.cuda(), ps, ptype_i).cpu()
+    assert rel_l2(dp, p.grad) < 2e-3, rel_l2(dp, p.grad)           # same boundary pixels; sums of ~1e4 terms each
+    # a patch that covers nothing (scale tiny, shifted out of the canvas) leaves the image untouched and has zero gradient
+    far = [(0.05, 0.0, 500.0, 500.0)] * B
+    assert torch.equal(eng.patch_apply(img.cuda(), patch.cuda(), _mats(P, far).cuda(), ptype_i).cpu(), img.clamp(0, 1))
+    assert eng.patch_grad(gout.cuda(), _mats(P, far).cuda(), ps, ptype_i).abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("prec", ["f16", "f32"])
+def test_patch_train_steps_match_oracle(prec):
+    """ART `_train_step` x 4 on a small ViT (untargeted, Adam): same sampled transformations, patch compared after the
+    steps.  lr is small here so that Adam's first steps do not saturate the clamp (the reference's lr = 5.0 makes every
+    element jump to 0 or 1 at step one: checked below by decision agreement)."""
+    P = pkg()
+    cfg, w, _, x, y = make_case(image_size=64, batch=6, r=0)
+    model = P.create_vit_model(cfg.num_labels, arch=P.ArchConfig(image_size=64, hidden=cfg.hidden, layers=cfg.layers, heads=cfg.heads,
+                                                                 mlp=cfg.mlp, num_labels=cfg.num_labels), precision=prec)
+    model.load_state_dict(w)
+    patch_mod = importlib.import_module(PKG + ".patch")
+    net = lambda z: O.vit_forward(w, cfg, O.normalise(z), None)
+    for lr, steps in ((0.02, 4), (5.0, 1)):
+        atk = patch_mod.AdversarialPatchPyTorch(P.LogitsModel(model), rotation_max=22.5, scale_min=0.3, scale_max=0.9, learning_rate=lr,
+                                                max_iter=steps, batch_size=6, patch_shape=(3, 16, 16), patch_type="circle",
+                                                targeted=False, verbose=False, seed=11)
+        ref_patch = torch.full((3, 16, 16), 0.5, requires_grad=True)
+        opt = torch.optim.Adam([ref_patch], lr=lr)
+        for _ in range(steps):
+            params = atk.sample_params(6)
+            ce = atk.train_step(x, y, params=params)
+            opt.zero_grad()
+            loss = -torch.nn.functional.cross_entropy(net(PO.overlay(x, ref_patch, "circle", params)), y)
+            loss.backward()
+            opt.step()
+            with torch.no_grad():
+                ref_patch.clamp_(0, 1)
+            assert abs(float(ce) + loss.item()) < (4e-3 if prec == "f16" else 2e-4) * abs(loss.item())
+        got = atk._patch.cpu()
+        if lr < 1:
+            assert (got - ref_patch.detach()).abs().max().item() < (2e-2 if prec == "f16" else 2e-3)
+        else:
+            inside = atk.patch_mask()[0] > 0.5              # elements the circular mask exposes receive a gradient
+            same = ((got - ref_patch.detach()).abs() < 1e-6)[:, inside].float().mean().item()
+            assert same > (0.97 if prec == "f16" else 0.995), same
+            assert set(torch.unique(got[:, inside]).tolist()) <= {0.0, 1.0}
+
+
+def test_vit_l16_full_depth_patch_gradient_small_batch():
+    """BASELINE config 5's model at full depth: ViT-L/16 (24 layers, hidden 1024, 16 heads, mlp 4096) + LoRA r = 16, one EoT
+    step on 2 images -- CE and d(CE)/d(patch) against the oracle (the patch gradient folds the whole 24-layer input
+    gradient through the warp)."""
+    P = pkg()
+    torch.set_num_threads(16)
+    cfg = O.OracleConfig(hidden=1024, layers=24, heads=16, mlp=4096, num_labels=21)
+    w = O.init_weights(cfg, seed=31)
+    lora = O.init_lora(cfg, r=16, targets=("q", "k", "v", "o", "fc2"), seed=32, b_std=0.02)
+    g = torch.Generator().manual_seed(33)
+    x = torch.rand(2, 3, 224, 224, generator=g)
+    y = torch.randint(0, 21, (2,), generator=g)
+    eng = make_engine(cfg, w, lora)
+    params = [(0.35, 12.0, 20.0, -31.0), (0.6, -8.0, -14.0, 9.0)]
+    patch = torch.rand(3, 32, 32, generator=g)
+    mats = _mats(P, params).cuda()
+    patched = eng.patch_apply(x.cuda(), patch.cuda(), mats, 1)
+    logits = eng.forward(patched, normalise=True).cpu()
+    ce = eng.loss_ce(y.cuda()).item()
+    gx, _ = eng.backward(True, False, tuple(x.shape))
+    dp = eng.patch_grad(gx, mats, 32, 1).cpu()
+    net = lambda z: O.vit_forward(w, cfg, O.normalise(z), lora)
+    ce_ref, dp_ref = PO.patch_loss_and_grad(net, x, y, patch, "circle", params)
+    assert abs(ce - ce_ref.item()) < 4e-3 * ce_ref.item()
+    assert rel_l2(dp, dp_ref) < 6e-3, rel_l2(dp, dp_ref)
+    assert rel_l2(logits, net(PO.overlay(x, patch, "circle", params))) < 4e-3
+
+
+def test_patch_attack_cli_synthetic(tmp_path):
+    import os
+    import patch_attack
+    patch_attack.main(["--model", "google_vit", "--source", "synthetic", "--output_dir", str(tmp_path), "--synthetic", "24",
+                       "--arch", "tiny", "--batch_size", "8", "--patch_size", "16", "--max_iter", "3", "--splits", "test",
+                       "--patch_type", "circle", "square"])
+    for pt in ("circle", "square"):
+        d = os.path.join(str(tmp_path), "google_vit", "synthetic", "test", f"patch_{pt}", "images")
+        assert len(os.listdir(d)) == 24
+        assert os.path.exists(os.path.join(str(tmp_path), "google_vit", "synthetic", "test", f"patch_{pt}", "patch.npy"))
