@@ -23,7 +23,7 @@ __all__ = ["ArchConfig", "Engine", "LoraSpec", "VitLoraError", "LIB_PATH", "IMAG
 def __getattr__(name):
     # the facade modules import torch.nn etc.; load them lazily
     import importlib
-    for mod in ("model", "attacks", "peft_compat", "optim", "io", "patch"):
+    for mod in ("model", "attacks", "peft_compat", "optim", "io", "patch", "swin"):
         try:
             m = importlib.import_module(f".{mod}", __name__)
         except ModuleNotFoundError:

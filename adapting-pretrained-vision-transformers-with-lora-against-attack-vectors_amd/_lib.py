@@ -67,6 +67,28 @@ SIGNATURES = {
     "vl_debug_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
 }
 
+class VLSwinConfig(C.Structure):
+    _fields_ = [("image_size", C.c_int32), ("patch_size", C.c_int32), ("embed_dim", C.c_int32), ("depths", C.c_int32 * 4),
+                ("heads", C.c_int32 * 4), ("window", C.c_int32), ("num_labels", C.c_int32), ("ln_eps", C.c_float),
+                ("lora_r", C.c_int32), ("lora_alpha", C.c_float), ("lora_targets", C.c_uint32), ("reserved", C.c_int32 * 4)]
+
+
+SIGNATURES.update({
+    "vl_swin_create": (C.c_int, [C.POINTER(VLSwinConfig), C.POINTER(C.c_void_p)]),
+    "vl_swin_destroy": (C.c_int, [C.c_void_p]),
+    "vl_swin_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "vl_swin_param_flat": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "vl_swin_param_tensor": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "vl_swin_set_normalization": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "vl_swin_plan": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
+    "vl_swin_set_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "vl_swin_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vl_swin_loss_ce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vl_swin_backward_input": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vl_swin_pgd_attack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_uint64,
+                                     C.c_void_p, C.c_void_p]),
+})
+
 _lib = None
 
 

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32 p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// LayerNorm (eps 1e-12, configuration_vit.py:58): one wave per row, D <= 1024
+constexpr int LNV = 8;       // float4 chunks per lane: rows up to 8 * 64 * 4 = 2048 features
+// LayerNorm (ViT eps 1e-12, configuration_vit.py:58; Swin 1e-5): one wave per row, D <= 2048
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ln_fwd_f32_kernel(const float* __restrict__ x, float* __restrict__ h,
                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -113,10 +114,10 @@ __global__ __launch_bounds__(256) void ln_fwd_f32_kernel(const float* __restrict
     if (row >= M) return;
     const float* xr = x + (int64_t)row * D;
     const int nv = D >> 2;
-    f32x4_t v[4];
+    f32x4_t v[LNV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < LNV; ++i) {
         const int c = lane + i * 64;
         v[i] = c < nv ? *(const f32x4_t*)(xr + c * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
         s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void ln_fwd_f32_kernel(const float* __restrict
     const float mean = wave_sum(s) / D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < LNV; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
 #pragma unroll
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void ln_fwd_f32_kernel(const float* __restrict
     const float rstd = 1.0f / sqrtf(wave_sum(q) / D + eps);
     if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < LNV; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
             const f32x4_t g = *(const f32x4_t*)(gamma + c * 4), b = *(const f32x4_t*)(beta + c * 4);
@@ -157,10 +158,10 @@ __global__ __launch_bounds__(256) void ln_bwd_f32_kernel(const float* __restrict
     const float mean = mean_in[row], rstd = rstd_in[row];
     const int64_t off = (int64_t)row * D;
     const int nv = D >> 2;
-    f32x4_t g[4], xh[4];
+    f32x4_t g[LNV], xh[LNV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < LNV; ++i) {
         const int c = lane + i * 64;
         g[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         xh[i] = g[i];
@@ -179,10 +180,10 @@ __global__ __launch_bounds__(256) void ln_bwd_f32_kernel(const float* __restrict
     }
     const float c1 = wave_sum(s1) / D, c2 = wave_sum(s2) / D;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < LNV; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
-            const f32x4_t r = *(const f32x4_t*)(dres + off + c * 4);
+            const f32x4_t r = dres ? *(const f32x4_t*)(dres + off + c * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
             f32x4_t o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = r[k] + rstd * (g[i][k] - c1 - xh[i][k] * c2);

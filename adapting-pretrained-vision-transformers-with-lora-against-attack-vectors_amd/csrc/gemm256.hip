@@ -25,6 +25,7 @@
 //   * W rows are permuted on the way into LDS so that a lane ends up with 16 ADJACENT output
 //     columns: the epilogue moves 16 bytes per lane per instruction.
 #include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "gemm_epi.h"
@@ -324,6 +325,7 @@ int g_num_cus = 0;
 
 // Choose how many 256-row tile rows stay "big"; the rest of the rows become 128-row tiles that
 // must fit one round (<= G workgroups).  cost = big rounds + 0.55 per small round.
+double g_tail_cost = 0.55;      // VITLORA_TAIL_COST: price of the 128-row tail launch in units of one round of 256-row tiles
 bool plan_tiles(int M, int N, int G, int* nbig, int* nsmall) {
     const int tilesN = N / BN, rows256 = M / 256, rows128 = M / 128;
     double best = 1e30;
@@ -332,7 +334,7 @@ bool plan_tiles(int M, int N, int G, int* nbig, int* nsmall) {
         const int big_rows = rows256 - give;
         const long nb = (long)big_rows * tilesN, ns = (long)(rows128 - 2 * big_rows) * tilesN;
         if (ns > G) break;
-        const double cost = (double)((nb + G - 1) / G) + (ns > 0 ? 0.55 : 0.0);
+        const double cost = (double)((nb + G - 1) / G) + (ns > 0 ? g_tail_cost : 0.0);
         if (cost < best - 1e-9) { best = cost; *nbig = (int)nb; *nsmall = (int)ns; ok = true; }
     }
     return ok;
@@ -384,6 +386,7 @@ bool gemm256_supports(const GemmArgs& a, int epi) {
 
 int gemm256_init() {
     g_attr_err256 = 0;
+    if (const char* tc = getenv("VITLORA_TAIL_COST")) g_tail_cost = atof(tc);
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)

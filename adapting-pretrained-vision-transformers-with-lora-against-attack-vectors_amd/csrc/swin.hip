@@ -1,0 +1,725 @@
+// Swin Transformer (Swin-T by default) + LoRA forward / backward-to-input / PGD behind the vl_swin_* C ABI
+// (BASELINE config 4; the reference lists Swin-T in README.md:53 but holds no code for it: the oracle is HF's
+// SwinForImageClassification built from a local SwinConfig, modeling_swin.py).  fp32 throughout: the GEMMs run on the
+// exact-f32 MFMA kernel of the parity mode (f32_kernels.hip), the windowed attention below is a HIP kernel of its own:
+//   * window partition, cyclic shift and their inverses are pure INDEX arithmetic inside the attention kernels
+//     (token p of window w of the rolled image -> row of the [B, H*W, C] activation), nothing is copied or rolled;
+//   * the shift mask (-100 between different regions, SwinLayer.get_attn_mask) and the relative position bias
+//     (table[(dy+6)*13 + (dx+6)][head]) are evaluated on the fly;
+//   * one wave per (image, window, head): lane = query (forward, dQ) or key (dK, dV); 49 tokens, head_dim 32.
+// This is the functional first form of the path (parity first); an fp16 MFMA form of the window kernels is the next step.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vitlora.h"
+#include "f32_kernels.h"
+#include "kernels.h"
+#include "model.h"
+#include "prof.h"
+
+namespace {
+
+constexpr int WS = 7, WT = 49, HDIM = 32, KLD = 33;
+
+__device__ __forceinline__ int win_row(int b, int w, int p, int H, int W, int shift) {
+    const int nwx = W / WS;
+    int y = (w / nwx) * WS + p / WS + shift, x = (w % nwx) * WS + p % WS + shift;
+    if (y >= H) y -= H;
+    if (x >= W) x -= W;
+    return (b * H + y) * W + x;
+}
+// region id of a position of the ROLLED image (SwinLayer.get_attn_mask): rows / columns >= H - 7 and >= H - shift
+__device__ __forceinline__ int win_region(int w, int p, int H, int W, int shift) {
+    const int nwx = W / WS;
+    const int y = (w / nwx) * WS + p / WS, x = (w % nwx) * WS + p % WS;
+    return ((y >= H - WS) + (y >= H - shift)) * 3 + (x >= W - WS) + (x >= W - shift);
+}
+__device__ __forceinline__ int bias_index(int pi, int pj) { return (pi / WS - pj / WS + WS - 1) * (2 * WS - 1) + (pi % WS - pj % WS + WS - 1); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward: ctx = softmax(q k^T / sqrt(32) + bias + mask) v per (image, window, head)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void win_attn_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ table,
+                                                           float* __restrict__ ctx, float* __restrict__ lse, int B, int H, int W,
+                                                           int C, int heads, int shift) {
+    __shared__ float sK[4][WT * KLD], sV[4][WT * KLD];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nW = (H / WS) * (W / WS);
+    const int64_t item = (int64_t)blockIdx.x * 4 + wv;
+    if (item >= (int64_t)B * nW * heads) return;
+    const int hd = (int)(item % heads);
+    const int w = (int)((item / heads) % nW);
+    const int b = (int)(item / ((int64_t)heads * nW));
+    const int p = lane < WT ? lane : WT - 1;
+    const int row = win_row(b, w, p, H, W, shift);
+    const float* src = qkv + (int64_t)row * 3 * C + hd * HDIM;
+    float q[HDIM];
+#pragma unroll
+    for (int d = 0; d < HDIM; d += 4) {
+        const f32x4 a = *(const f32x4*)(src + d), k4 = *(const f32x4*)(src + C + d), v4 = *(const f32x4*)(src + 2 * C + d);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            q[d + e] = a[e];
+            if (lane < WT) { sK[wv][p * KLD + d + e] = k4[e]; sV[wv][p * KLD + d + e] = v4[e]; }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int reg_i = shift ? win_region(w, p, H, W, shift) : 0;
+    float s[WT], mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int d = 0; d < HDIM; ++d) a = fmaf(q[d], sK[wv][j * KLD + d], a);
+        a = a * 0.17677669529663687f + table[bias_index(p, j) * heads + hd];
+        if (shift && win_region(w, j, H, W, shift) != reg_i) a += -100.0f;
+        s[j] = a;
+        mx = fmaxf(mx, a);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < WT; ++j) { s[j] = expf(s[j] - mx); sum += s[j]; }
+    const float inv = 1.f / sum;
+    float o[HDIM];
+#pragma unroll
+    for (int d = 0; d < HDIM; ++d) o[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+        const float pj = s[j] * inv;
+#pragma unroll
+        for (int d = 0; d < HDIM; ++d) o[d] = fmaf(pj, sV[wv][j * KLD + d], o[d]);
+    }
+    if (lane < WT) {
+        float* dst = ctx + (int64_t)row * C + hd * HDIM;
+#pragma unroll
+        for (int d = 0; d < HDIM; d += 4) *(f32x4*)(dst + d) = f32x4{o[d], o[d + 1], o[d + 2], o[d + 3]};
+        lse[(int64_t)row * heads + hd] = mx + logf(sum);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward: dq (lane = query), then dk, dv (lane = key); P recomputed from the saved log-sum-exp
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void win_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ table,
+                                                           const float* __restrict__ ctx, const float* __restrict__ dctx,
+                                                           const float* __restrict__ lse, float* __restrict__ dqkv, int B, int H,
+                                                           int W, int C, int heads, int shift) {
+    __shared__ float sQ[2][WT * KLD], sK[2][WT * KLD], sV[2][WT * KLD], sdO[2][WT * KLD], sL[2][64], sD[2][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nW = (H / WS) * (W / WS);
+    const int64_t item = (int64_t)blockIdx.x * 2 + wv;
+    if (item >= (int64_t)B * nW * heads) return;
+    const int hd = (int)(item % heads);
+    const int w = (int)((item / heads) % nW);
+    const int b = (int)(item / ((int64_t)heads * nW));
+    const int p = lane < WT ? lane : WT - 1;
+    const int row = win_row(b, w, p, H, W, shift);
+    const float* src = qkv + (int64_t)row * 3 * C + hd * HDIM;
+    const float* dsrc = dctx + (int64_t)row * C + hd * HDIM;
+    const float* osrc = ctx + (int64_t)row * C + hd * HDIM;
+    float a_[HDIM], b_[HDIM];          // pass 1: q_i, dO_i ; pass 2: k_j, v_j
+    float delta = 0.f;
+#pragma unroll
+    for (int d = 0; d < HDIM; d += 4) {
+        const f32x4 q4 = *(const f32x4*)(src + d), k4 = *(const f32x4*)(src + C + d), v4 = *(const f32x4*)(src + 2 * C + d);
+        const f32x4 g4 = *(const f32x4*)(dsrc + d), o4 = *(const f32x4*)(osrc + d);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a_[d + e] = q4[e]; b_[d + e] = g4[e];
+            delta = fmaf(g4[e], o4[e], delta);
+            if (lane < WT) {
+                sQ[wv][p * KLD + d + e] = q4[e]; sK[wv][p * KLD + d + e] = k4[e];
+                sV[wv][p * KLD + d + e] = v4[e]; sdO[wv][p * KLD + d + e] = g4[e];
+            }
+        }
+    }
+    const float lse_i = lse[(int64_t)row * heads + hd];
+    if (lane < WT) { sL[wv][p] = lse_i; sD[wv][p] = delta; }
+    __builtin_amdgcn_wave_barrier();
+    const int reg_p = shift ? win_region(w, p, H, W, shift) : 0;
+    const float scale = 0.17677669529663687f;
+    // ---- pass 1: lane = query i ----
+    float acc[HDIM];
+#pragma unroll
+    for (int d = 0; d < HDIM; ++d) acc[d] = 0.f;
+    for (int j = 0; j < WT; ++j) {
+        float sdot = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < HDIM; ++d) { sdot = fmaf(a_[d], sK[wv][j * KLD + d], sdot); dp = fmaf(b_[d], sV[wv][j * KLD + d], dp); }
+        float sc = sdot * scale + table[bias_index(p, j) * heads + hd];
+        if (shift && win_region(w, j, H, W, shift) != reg_p) sc += -100.0f;
+        const float pr = expf(sc - lse_i);
+        const float ds = pr * (dp - delta) * scale;
+#pragma unroll
+        for (int d = 0; d < HDIM; ++d) acc[d] = fmaf(ds, sK[wv][j * KLD + d], acc[d]);
+    }
+    float* dst = dqkv + (int64_t)row * 3 * C + hd * HDIM;
+    if (lane < WT) {
+#pragma unroll
+        for (int d = 0; d < HDIM; d += 4) *(f32x4*)(dst + d) = f32x4{acc[d], acc[d + 1], acc[d + 2], acc[d + 3]};
+    }
+    // ---- pass 2: lane = key j ----
+#pragma unroll
+    for (int d = 0; d < HDIM; ++d) { a_[d] = sK[wv][p * KLD + d]; b_[d] = sV[wv][p * KLD + d]; }
+    float dk[HDIM], dv[HDIM];
+#pragma unroll
+    for (int d = 0; d < HDIM; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+    for (int i = 0; i < WT; ++i) {
+        float sdot = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < HDIM; ++d) { sdot = fmaf(sQ[wv][i * KLD + d], a_[d], sdot); dp = fmaf(sdO[wv][i * KLD + d], b_[d], dp); }
+        float sc = sdot * scale + table[bias_index(i, p) * heads + hd];
+        if (shift && win_region(w, i, H, W, shift) != reg_p) sc += -100.0f;
+        const float pr = expf(sc - sL[wv][i]);
+        const float ds = pr * (dp - sD[wv][i]) * scale;
+#pragma unroll
+        for (int d = 0; d < HDIM; ++d) { dk[d] = fmaf(ds, sQ[wv][i * KLD + d], dk[d]); dv[d] = fmaf(pr, sdO[wv][i * KLD + d], dv[d]); }
+    }
+    if (lane < WT) {
+#pragma unroll
+        for (int d = 0; d < HDIM; d += 4) {
+            *(f32x4*)(dst + C + d) = f32x4{dk[d], dk[d + 1], dk[d + 2], dk[d + 3]};
+            *(f32x4*)(dst + 2 * C + d) = f32x4{dv[d], dv[d + 1], dv[d + 2], dv[d + 3]};
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// patch embedding gather (Conv2d k = s = P as a GEMM), patch merging gather / scatter, mean-pool head
+// ---------------------------------------------------------------------------------------------------------------
+// merged[b, (y/2)*(W/2) + x/2, q*C + c] = x[b, y, x, c], q = (x & 1) * 2 + (y & 1)   (SwinPatchMerging.forward: col-major quad order)
+__global__ void merge_gather_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int H, int W, int C, int inverse) {
+    const int64_t total = (int64_t)B * H * W * C;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int c = (int)(t % C);
+        int64_t r = t / C;
+        const int xx = (int)(r % W); r /= W;
+        const int yy = (int)(r % H);
+        const int b = (int)(r / H);
+        const int64_t m = ((int64_t)b * (H / 2) + yy / 2) * (W / 2) + xx / 2;
+        const int64_t o = m * 4 * C + ((xx & 1) * 2 + (yy & 1)) * C + c;
+        if (inverse) out[t] = x[o]; else out[o] = x[t];
+    }
+}
+// pooled[b][c] = mean over the L tokens of h[b][t][c]; inverse: dh[b][t][c] = dpooled[b][c] / L
+__global__ void mean_pool_kernel(const float* __restrict__ h, float* __restrict__ pooled, int B, int L, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    float s = 0.f;
+    for (int t = 0; t < L; ++t) s += h[((int64_t)b * L + t) * C + c];
+    pooled[i] = s / L;
+}
+__global__ void mean_pool_bwd_kernel(const float* __restrict__ dpooled, float* __restrict__ dh, int B, int L, int C) {
+    const int64_t total = (int64_t)B * L * C;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int b = (int)(i / ((int64_t)L * C));
+    dh[i] = dpooled[b * C + c] / L;
+}
+
+// logits[b][c] = pooled[b] . Wc[c] + bc[c]   (one wave per output);  dpooled[b][d] = sum_c dlogits[b][c] Wc[c][d]
+__global__ void cls_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ Wc, const float* __restrict__ bc,
+                               float* __restrict__ logits, int B, int C, int D) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= B * C) return;
+    const int b = o / C, c = o - b * C;
+    float a = 0.f;
+    for (int d = lane; d < D; d += 64) a = fmaf(pooled[(int64_t)b * D + d], Wc[(int64_t)c * D + d], a);
+    a = wave_sum(a);
+    if (lane == 0) logits[o] = a + bc[c];
+}
+__global__ void cls_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ Wc, float* __restrict__ dpooled, int B,
+                               int C, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * D) return;
+    const int b = i / D, d = i - b * D;
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a = fmaf(dlogits[(int64_t)b * C + c], Wc[(int64_t)c * D + d], a);
+    dpooled[i] = a;
+}
+
+inline unsigned nblk(int64_t n, int t, int cap) {
+    int64_t b = (n + t - 1) / t;
+    return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+struct SLora { int row_off, out; float *A, *B; };            // one adapted module inside a (fused) linear
+struct SLin {
+    int out = 0, in = 0;
+    float *W = nullptr, *b = nullptr;
+    std::vector<SLora> slots;
+};
+struct SBlock {
+    SLin qkv, o, fc1, fc2;
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *table;
+    // saved by the forward
+    float *xa, *xb, *mean1, *rstd1, *mean2, *rstd2, *qkvbuf, *ctx, *lse, *z;
+};
+struct SStage {
+    int C, H, heads, depth;
+    std::vector<SBlock> blocks;
+    // downsample (absent after the last stage)
+    float *mg_g = nullptr, *mg_b = nullptr, *Wred = nullptr;
+    float *mg = nullptr, *mmean = nullptr, *mrstd = nullptr;    // saved
+};
+
+}  // namespace
+
+struct vl_swin {
+    vl_swin_config cfg;
+    int S, P, G0, E, C, r;
+    float scaling;
+    std::vector<SStage> stages;
+    float *Wpe, *bpe, *eg, *eb, *fg, *fb, *Wc, *bc;
+    float* flat = nullptr;
+    int64_t flat_n = 0;
+    std::vector<void*> allocs;
+    // workspace
+    int max_batch = 0, cur_B = 0, cur_norm = 0, have_loss = 0;
+    float *patches, *emb, *emean, *erstd, *xlast, *fmean, *frstd, *hfin, *pooled, *logits, *dlogits, *loss, *loss_img, *dpooled;
+    float *h, *a, *t, *u, *g0, *g1, *dbig, *dqkv, *grad_img, *stage_x0, *stage_adv;
+    int64_t* stage_labels;
+    int* err_flag = nullptr;
+    float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+};
+
+namespace {
+
+template <typename Tp>
+int salloc(vl_swin* m, Tp** p, size_t n) {
+    void* q = nullptr;
+    if (hipMalloc(&q, n * sizeof(Tp) + 256) != hipSuccess) return vl_fail(VL_ERR_HIP, "hipMalloc(%zu) failed", n * sizeof(Tp));
+    if (hipMemset(q, 0, n * sizeof(Tp) + 256) != hipSuccess) return vl_fail(VL_ERR_HIP, "hipMemset failed");
+    m->allocs.push_back(q);
+    *p = (Tp*)q;
+    return VL_OK;
+}
+
+GemmF32 gm(const float* A, int lda, const float* W, int ldw, int transW, int M, int N, int K, float* C, int ldc) {
+    GemmF32 g;
+    memset(&g, 0, sizeof g);
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.transW = transW;
+    g.M = M; g.Mstore = M; g.N = N; g.K = K; g.alpha = 1.f; g.C = C; g.ldc = ldc;
+    return g;
+}
+
+// y = x W^T + b (+ R) + sum over adapted modules of s * (x A^T) B^T        (peft lora.Linear, eval mode)
+void lin_fwd(vl_swin* m, const SLin& ln, const float* x, int M, float* y, const float* R, hipStream_t s) {
+    GemmF32 g = gm(x, ln.in, ln.W, ln.in, 0, M, ln.out, ln.in, y, ln.out);
+    g.bias = ln.b; g.R = R; g.ldr = ln.out;
+    k_gemm_f32(g, s);
+    for (const SLora& sl : ln.slots) {
+        k_gemm_f32(gm(x, ln.in, sl.A, ln.in, 0, M, m->r, ln.in, m->t, 64), s);
+        GemmF32 u = gm(m->t, 64, sl.B, m->r, 0, M, sl.out, m->r, y + sl.row_off, ln.out);
+        u.alpha = m->scaling; u.R = y + sl.row_off; u.ldr = ln.out;
+        k_gemm_f32(u, s);
+    }
+}
+// dx = dy W + sum of s * (dy B) A
+void lin_dgrad(vl_swin* m, const SLin& ln, const float* dy, int M, float* dx, hipStream_t s) {
+    k_gemm_f32(gm(dy, ln.out, ln.W, ln.in, 1, M, ln.in, ln.out, dx, ln.in), s);
+    for (const SLora& sl : ln.slots) {
+        k_gemm_f32(gm(dy + sl.row_off, ln.out, sl.B, m->r, 1, M, m->r, sl.out, m->u, 64), s);
+        GemmF32 a = gm(m->u, 64, sl.A, ln.in, 1, M, ln.in, m->r, dx, ln.in);
+        a.alpha = m->scaling; a.R = dx; a.ldr = ln.in;
+        k_gemm_f32(a, s);
+    }
+}
+
+int parse2(const char* name, const char* pfx, int* a, const char** rest) {
+    const size_t n = strlen(pfx);
+    if (strncmp(name, pfx, n) != 0) return 0;
+    char* end = nullptr;
+    long v = strtol(name + n, &end, 10);
+    if (end == name + n || *end != '.') return 0;
+    *a = (int)v; *rest = end + 1;
+    return 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vl_swin_create(const vl_swin_config* cfg, vl_swin** out) {
+    if (!cfg || !out) return vl_fail(VL_ERR_ARG, "null argument");
+    if (cfg->window != WS) return vl_fail(VL_ERR_UNSUPPORTED, "window must be 7");
+    if (cfg->image_size % cfg->patch_size) return vl_fail(VL_ERR_UNSUPPORTED, "image_size %% patch_size != 0");
+    if (cfg->lora_r < 0 || cfg->lora_r > 16 || cfg->lora_r % 4) return vl_fail(VL_ERR_UNSUPPORTED, "lora_r must be 0, 4, 8, 12 or 16");
+    int res = cfg->image_size / cfg->patch_size;
+    for (int i = 0; i < 4; ++i) {
+        const int Cst = cfg->embed_dim << i;
+        if (cfg->depths[i] <= 0 || cfg->heads[i] <= 0 || Cst != cfg->heads[i] * HDIM)
+            return vl_fail(VL_ERR_UNSUPPORTED, "stage %d: head_dim must be 32 (dim %d, heads %d)", i, Cst, cfg->heads[i]);
+        if (res % WS) return vl_fail(VL_ERR_UNSUPPORTED, "stage %d: resolution %d is not a multiple of the window", i, res);
+        if (i < 3 && (res & 1)) return vl_fail(VL_ERR_UNSUPPORTED, "stage %d: odd resolution cannot be merged", i);
+        if (4 * Cst > 2048 && i < 3) return vl_fail(VL_ERR_UNSUPPORTED, "patch-merging width exceeds the LayerNorm kernel");
+        if (i < 3) res /= 2;
+    }
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (int e = f32_init(dev)) return vl_fail(VL_ERR_HIP, "f32_init failed (%d)", e);
+    vl_swin* m = new vl_swin();
+    m->cfg = *cfg;
+    m->S = cfg->image_size; m->P = cfg->patch_size; m->G0 = m->S / m->P; m->E = cfg->embed_dim; m->C = cfg->num_labels;
+    m->r = cfg->lora_targets ? cfg->lora_r : 0;
+    m->scaling = m->r ? cfg->lora_alpha / (float)m->r : 0.f;
+    int rc;
+#define A_(p, n) if ((rc = salloc(m, &(p), (size_t)(n))) != VL_OK) { vl_swin_destroy(m); return rc; }
+    const int PK = 3 * m->P * m->P;
+    A_(m->Wpe, (size_t)m->E * PK); A_(m->bpe, m->E); A_(m->eg, m->E); A_(m->eb, m->E);
+    // flat LoRA buffer layout: [stage][block][target q,k,v,o,fc1,fc2]{A, B}
+    int64_t off = 0;
+    m->stages.resize(4);
+    res = m->G0;
+    for (int i = 0; i < 4; ++i) {
+        SStage& st = m->stages[i];
+        st.C = m->E << i; st.H = res; st.heads = cfg->heads[i]; st.depth = cfg->depths[i];
+        st.blocks.resize(st.depth);
+        const int Cs = st.C;
+        for (SBlock& bk : st.blocks) {
+            bk.qkv.out = 3 * Cs; bk.qkv.in = Cs; bk.o.out = Cs; bk.o.in = Cs;
+            bk.fc1.out = 4 * Cs; bk.fc1.in = Cs; bk.fc2.out = Cs; bk.fc2.in = 4 * Cs;
+            for (SLin* ln : {&bk.qkv, &bk.o, &bk.fc1, &bk.fc2}) { A_(ln->W, (size_t)ln->out * ln->in); A_(ln->b, ln->out); }
+            A_(bk.ln1_g, Cs); A_(bk.ln1_b, Cs); A_(bk.ln2_g, Cs); A_(bk.ln2_b, Cs);
+            A_(bk.table, (size_t)(2 * WS - 1) * (2 * WS - 1) * st.heads);
+            if (m->r) {
+                SLin* lins[6] = {&bk.qkv, &bk.qkv, &bk.qkv, &bk.o, &bk.fc1, &bk.fc2};
+                const int rows[6] = {0, Cs, 2 * Cs, 0, 0, 0}, outs[6] = {Cs, Cs, Cs, Cs, 4 * Cs, Cs};
+                for (int ti = 0; ti < 6; ++ti) {
+                    if (!(cfg->lora_targets & kTargetBits[ti])) continue;
+                    SLora sl;
+                    sl.row_off = rows[ti]; sl.out = outs[ti]; sl.A = nullptr; sl.B = nullptr;
+                    lins[ti]->slots.push_back(sl);
+                    off += (int64_t)m->r * lins[ti]->in + (int64_t)sl.out * m->r;
+                }
+            }
+        }
+        if (i < 3) { A_(st.mg_g, 4 * Cs); A_(st.mg_b, 4 * Cs); A_(st.Wred, (size_t)2 * Cs * 4 * Cs); res /= 2; }
+    }
+    const int Cl = m->E << 3;
+    A_(m->fg, Cl); A_(m->fb, Cl); A_(m->Wc, (size_t)m->C * Cl); A_(m->bc, m->C);
+    m->flat_n = off;
+    A_(m->flat, (size_t)(off > 0 ? off : 4));
+#undef A_
+    // slot pointers are taken after the vectors stopped growing
+    {
+        int64_t o2 = 0;
+        for (SStage& st : m->stages)
+            for (SBlock& bk : st.blocks)
+                for (SLin* ln : {&bk.qkv, &bk.o, &bk.fc1, &bk.fc2})
+                    for (SLora& sl : ln->slots) {
+                        sl.A = m->flat + o2; o2 += (int64_t)m->r * ln->in;
+                        sl.B = m->flat + o2; o2 += (int64_t)sl.out * m->r;
+                    }
+        // NOTE: the loop above visits q, k, v (slots of qkv), o, fc1, fc2 in the same order the offsets were handed out
+    }
+    if (hipHostMalloc((void**)&m->err_flag, 64, hipHostMallocMapped) != hipSuccess) { vl_swin_destroy(m); return vl_fail(VL_ERR_HIP, "hipHostMalloc failed"); }
+    *m->err_flag = 0;
+    *out = m;
+    return VL_OK;
+}
+
+int vl_swin_destroy(vl_swin* m) {
+    if (!m) return VL_OK;
+    for (void* p : m->allocs) (void)hipFree(p);
+    if (m->err_flag) (void)hipHostFree(m->err_flag);
+    delete m;
+    return VL_OK;
+}
+
+// HF-4.55.2 key names of SwinForImageClassification ("swin.encoder.layers.S.blocks.B.attention.self.query.weight", ...)
+int vl_swin_load_tensor(vl_swin* m, const char* name, const float* src, int64_t numel, void* stream) {
+    if (!m || !name || !src) return vl_fail(VL_ERR_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    auto copyf = [&](float* dst, int64_t n) -> int {
+        if (n != numel) return vl_fail(VL_ERR_ARG, "%s: expected %lld elements, got %lld", name, (long long)n, (long long)numel);
+        HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return VL_OK;
+    };
+    const int PK = 3 * m->P * m->P, Cl = m->E << 3;
+    if (!strcmp(name, "swin.embeddings.patch_embeddings.projection.weight")) return copyf(m->Wpe, (int64_t)m->E * PK);
+    if (!strcmp(name, "swin.embeddings.patch_embeddings.projection.bias")) return copyf(m->bpe, m->E);
+    if (!strcmp(name, "swin.embeddings.norm.weight")) return copyf(m->eg, m->E);
+    if (!strcmp(name, "swin.embeddings.norm.bias")) return copyf(m->eb, m->E);
+    if (!strcmp(name, "swin.layernorm.weight")) return copyf(m->fg, Cl);
+    if (!strcmp(name, "swin.layernorm.bias")) return copyf(m->fb, Cl);
+    if (!strcmp(name, "classifier.weight")) return copyf(m->Wc, (int64_t)m->C * Cl);
+    if (!strcmp(name, "classifier.bias")) return copyf(m->bc, m->C);
+    int si = 0, bi = 0;
+    const char *rest = nullptr, *rest2 = nullptr;
+    if (!parse2(name, "swin.encoder.layers.", &si, &rest) || si < 0 || si > 3) return vl_fail(VL_ERR_ARG, "unknown tensor name: %s", name);
+    SStage& st = m->stages[si];
+    const int Cs = st.C;
+    if (!strcmp(rest, "downsample.norm.weight") && si < 3) return copyf(st.mg_g, 4 * Cs);
+    if (!strcmp(rest, "downsample.norm.bias") && si < 3) return copyf(st.mg_b, 4 * Cs);
+    if (!strcmp(rest, "downsample.reduction.weight") && si < 3) return copyf(st.Wred, (int64_t)2 * Cs * 4 * Cs);
+    if (!parse2(rest, "blocks.", &bi, &rest2) || bi < 0 || bi >= st.depth) return vl_fail(VL_ERR_ARG, "unknown tensor name: %s", name);
+    SBlock& bk = st.blocks[bi];
+    if (!strcmp(rest2, "layernorm_before.weight")) return copyf(bk.ln1_g, Cs);
+    if (!strcmp(rest2, "layernorm_before.bias")) return copyf(bk.ln1_b, Cs);
+    if (!strcmp(rest2, "layernorm_after.weight")) return copyf(bk.ln2_g, Cs);
+    if (!strcmp(rest2, "layernorm_after.bias")) return copyf(bk.ln2_b, Cs);
+    if (!strcmp(rest2, "attention.self.relative_position_bias_table")) return copyf(bk.table, (int64_t)169 * st.heads);
+    struct { const char* mod; SLin* ln; int row_off, rows; } mods[6] = {
+        {"attention.self.query.", &bk.qkv, 0, Cs}, {"attention.self.key.", &bk.qkv, Cs, Cs}, {"attention.self.value.", &bk.qkv, 2 * Cs, Cs},
+        {"attention.output.dense.", &bk.o, 0, Cs}, {"intermediate.dense.", &bk.fc1, 0, 4 * Cs}, {"output.dense.", &bk.fc2, 0, Cs}};
+    for (auto& md : mods) {
+        const size_t n = strlen(md.mod);
+        if (strncmp(rest2, md.mod, n) != 0) continue;
+        if (!strcmp(rest2 + n, "weight")) return copyf(md.ln->W + (size_t)md.row_off * md.ln->in, (int64_t)md.rows * md.ln->in);
+        if (!strcmp(rest2 + n, "bias")) return copyf(md.ln->b + md.row_off, md.rows);
+    }
+    return vl_fail(VL_ERR_ARG, "unknown tensor name: %s", name);
+}
+
+int vl_swin_param_flat(vl_swin* m, float** ptr, int64_t* numel) {
+    if (!m) return vl_fail(VL_ERR_ARG, "null model");
+    if (ptr) *ptr = m->flat;
+    if (numel) *numel = m->flat_n;
+    return VL_OK;
+}
+
+int vl_swin_param_tensor(vl_swin* m, int stage, int block, uint32_t target, int which, float** ptr, int64_t* numel) {
+    if (!m || !ptr || !numel) return vl_fail(VL_ERR_ARG, "null argument");
+    if (stage < 0 || stage > 3 || block < 0 || block >= m->stages[stage].depth) return vl_fail(VL_ERR_ARG, "stage / block out of range");
+    SBlock& bk = m->stages[stage].blocks[block];
+    SLin* lins[6] = {&bk.qkv, &bk.qkv, &bk.qkv, &bk.o, &bk.fc1, &bk.fc2};
+    const int Cs = m->stages[stage].C;
+    const int rows[6] = {0, Cs, 2 * Cs, 0, 0, 0};
+    for (int ti = 0; ti < 6; ++ti) {
+        if (kTargetBits[ti] != target) continue;
+        for (SLora& sl : lins[ti]->slots)
+            if (sl.row_off == rows[ti]) {
+                *ptr = which == 0 ? sl.A : sl.B;
+                *numel = which == 0 ? (int64_t)m->r * lins[ti]->in : (int64_t)sl.out * m->r;
+                return VL_OK;
+            }
+    }
+    return vl_fail(VL_ERR_ARG, "target 0x%x has no adapter", target);
+}
+
+int vl_swin_set_normalization(vl_swin* m, const float mean[3], const float stdv[3]) {
+    if (!m || !mean || !stdv) return vl_fail(VL_ERR_ARG, "null argument");
+    for (int c = 0; c < 3; ++c) { if (!(stdv[c] > 0.f)) return vl_fail(VL_ERR_ARG, "std must be positive"); m->mean[c] = mean[c]; m->stdv[c] = stdv[c]; }
+    return VL_OK;
+}
+
+static size_t swin_carve(vl_swin* m, int B, char* base) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) -> float* {
+        char* p = base ? base + off : nullptr;
+        off += (size_t)round_up((int64_t)bytes, 256);
+        return (float*)p;
+    };
+    const int L0 = m->G0 * m->G0, PK = 3 * m->P * m->P;
+    const int64_t R0 = round_up((int64_t)B * L0, 64);
+    m->patches = take((size_t)R0 * PK * 4);
+    m->emb = take((size_t)R0 * m->E * 4); m->emean = take((size_t)R0 * 4); m->erstd = take((size_t)R0 * 4);
+    size_t big = 0;
+    for (int i = 0; i < 4; ++i) {
+        SStage& st = m->stages[i];
+        const int64_t R = round_up((int64_t)B * st.H * st.H, 64);
+        for (SBlock& bk : st.blocks) {
+            bk.xa = take((size_t)R * st.C * 4); bk.xb = take((size_t)R * st.C * 4);
+            bk.mean1 = take((size_t)R * 4); bk.rstd1 = take((size_t)R * 4); bk.mean2 = take((size_t)R * 4); bk.rstd2 = take((size_t)R * 4);
+            bk.qkvbuf = take((size_t)R * 3 * st.C * 4); bk.ctx = take((size_t)R * st.C * 4);
+            bk.lse = take((size_t)R * st.heads * 4); bk.z = take((size_t)R * 4 * st.C * 4);
+        }
+        if (i < 3) { st.mg = take((size_t)R / 4 * 4 * st.C * 4 + 1024); st.mmean = take((size_t)R); st.mrstd = take((size_t)R); }
+        if ((size_t)R * 4 * st.C > big) big = (size_t)R * 4 * st.C;
+    }
+    const int Cl = m->E << 3, Ll = m->stages[3].H * m->stages[3].H;
+    m->xlast = take((size_t)round_up((int64_t)B * Ll, 64) * Cl * 4);
+    m->fmean = take((size_t)B * Ll * 4 + 256); m->frstd = take((size_t)B * Ll * 4 + 256);
+    m->hfin = take((size_t)round_up((int64_t)B * Ll, 64) * Cl * 4);
+    m->pooled = take((size_t)B * Cl * 4); m->dpooled = take((size_t)B * Cl * 4);
+    m->logits = take((size_t)B * m->C * 4); m->dlogits = take((size_t)B * m->C * 4);
+    m->loss = take(256); m->loss_img = take((size_t)B * 4);
+    m->h = take(big * 4); m->a = take(big * 4); m->dbig = take(big * 4);
+    m->dqkv = take(big * 4);
+    m->t = take((size_t)R0 * 64 * 4); m->u = take((size_t)R0 * 64 * 4);
+    m->g0 = take((size_t)R0 * m->E * 4 + big); m->g1 = take((size_t)R0 * m->E * 4 + big);
+    const size_t img = (size_t)B * 3 * m->S * m->S * 4;
+    m->grad_img = take(img); m->stage_x0 = take(img); m->stage_adv = take(img);
+    m->stage_labels = (int64_t*)take((size_t)B * 8);
+    return off;
+}
+
+int vl_swin_plan(vl_swin* m, int max_batch, size_t* bytes) {
+    if (!m || !bytes || max_batch <= 0) return vl_fail(VL_ERR_ARG, "bad argument");
+    *bytes = swin_carve(m, max_batch, nullptr);
+    m->max_batch = -max_batch;          // planned, not armed
+    return VL_OK;
+}
+
+int vl_swin_set_workspace(vl_swin* m, void* ws, size_t bytes) {
+    if (!m || !ws) return vl_fail(VL_ERR_ARG, "null argument");
+    if (m->max_batch >= 0) return vl_fail(VL_ERR_STATE, "vl_swin_set_workspace before vl_swin_plan");
+    const int B = -m->max_batch;
+    if (((uintptr_t)ws) & 255) return vl_fail(VL_ERR_ARG, "workspace must be 256-byte aligned");
+    const size_t need = swin_carve(m, B, nullptr);
+    if (bytes < need) return vl_fail(VL_ERR_ARG, "workspace too small: %zu < %zu", bytes, need);
+    swin_carve(m, B, (char*)ws);
+    if (hipMemset(ws, 0, need) != hipSuccess) return vl_fail(VL_ERR_HIP, "hipMemset(workspace) failed");
+    m->max_batch = B;
+    m->cur_B = 0;
+    return VL_OK;
+}
+
+static int swin_forward(vl_swin* m, const float* x, int B, int normalise, hipStream_t s) {
+    if (B <= 0 || B > m->max_batch) return vl_fail(VL_ERR_STATE, "batch %d exceeds planned workspace (%d)", B, m->max_batch);
+    const int L0 = m->G0 * m->G0, PK = 3 * m->P * m->P;
+    // patch embedding: Conv2d(3, E, k = s = P) as a GEMM over gathered patches, then LayerNorm (SwinEmbeddings)
+    k_patch_gather_f32(x, m->patches, B, m->S, m->P, normalise, m->mean, m->stdv, s);
+    GemmF32 g = gm(m->patches, PK, m->Wpe, PK, 0, B * L0, m->E, PK, m->emb, m->E);
+    g.bias = m->bpe;
+    k_gemm_f32(g, s);
+    k_ln_fwd_f32(m->emb, m->stages[0].blocks[0].xa, m->emean, m->erstd, m->eg, m->eb, B * L0, m->E, m->cfg.ln_eps, s);
+    for (int i = 0; i < 4; ++i) {
+        SStage& st = m->stages[i];
+        const int Cs = st.C, Hs = st.H, M = B * Hs * Hs;
+        const int nW = (Hs / WS) * (Hs / WS);
+        for (int bi = 0; bi < st.depth; ++bi) {
+            SBlock& bk = st.blocks[bi];
+            const int shift = (bi & 1) && Hs > WS ? WS / 2 : 0;          // SwinLayer: no shift when the window covers the map
+            float* xout = bi + 1 < st.depth ? st.blocks[bi + 1].xa : (i < 3 ? m->dbig : m->xlast);
+            k_ln_fwd_f32(bk.xa, m->h, bk.mean1, bk.rstd1, bk.ln1_g, bk.ln1_b, M, Cs, m->cfg.ln_eps, s);
+            lin_fwd(m, bk.qkv, m->h, M, bk.qkvbuf, nullptr, s);
+            hipLaunchKernelGGL(win_attn_fwd_kernel, dim3(nblk((int64_t)B * nW * st.heads, 4, 1 << 30)), dim3(256), 0, s, bk.qkvbuf,
+                               bk.table, bk.ctx, bk.lse, B, Hs, Hs, Cs, st.heads, shift);
+            lin_fwd(m, bk.o, bk.ctx, M, bk.xb, bk.xa, s);
+            k_ln_fwd_f32(bk.xb, m->h, bk.mean2, bk.rstd2, bk.ln2_g, bk.ln2_b, M, Cs, m->cfg.ln_eps, s);
+            lin_fwd(m, bk.fc1, m->h, M, bk.z, nullptr, s);
+            k_gelu_fwd_f32(bk.z, m->a, (int64_t)M * 4 * Cs, s);
+            lin_fwd(m, bk.fc2, m->a, M, xout, bk.xb, s);
+        }
+        if (i < 3) {        // SwinPatchMerging: 2x2 neighbourhood -> 4C, LayerNorm, Linear(4C -> 2C, no bias)
+            hipLaunchKernelGGL(merge_gather_kernel, dim3(nblk((int64_t)M * Cs, 256, 8192)), dim3(256), 0, s, m->dbig, st.mg, B, Hs,
+                               Hs, Cs, 0);
+            k_ln_fwd_f32(st.mg, m->h, st.mmean, st.mrstd, st.mg_g, st.mg_b, M / 4, 4 * Cs, m->cfg.ln_eps, s);
+            k_gemm_f32(gm(m->h, 4 * Cs, st.Wred, 4 * Cs, 0, M / 4, 2 * Cs, 4 * Cs, m->stages[i + 1].blocks[0].xa, 2 * Cs), s);
+        }
+    }
+    // final LayerNorm over every token, mean pool, classifier (SwinModel.pooler + SwinForImageClassification.classifier)
+    const int Cl = m->E << 3, Ll = m->stages[3].H * m->stages[3].H;
+    k_ln_fwd_f32(m->xlast, m->hfin, m->fmean, m->frstd, m->fg, m->fb, B * Ll, Cl, m->cfg.ln_eps, s);
+    hipLaunchKernelGGL(mean_pool_kernel, dim3(nblk((int64_t)B * Cl, 256, 1 << 30)), dim3(256), 0, s, m->hfin, m->pooled, B, Ll, Cl);
+    hipLaunchKernelGGL(cls_fwd_kernel, dim3(nblk((int64_t)B * m->C, 4, 1 << 30)), dim3(256), 0, s, m->pooled, m->Wc, m->bc, m->logits, B,
+                       m->C, Cl);
+    m->cur_B = B; m->cur_norm = normalise; m->have_loss = 0;
+    return VL_OK;
+}
+
+static int swin_backward(vl_swin* m, float* grad_x, hipStream_t s) {
+    if (!m->have_loss) return vl_fail(VL_ERR_STATE, "backward before vl_swin_loss_ce");
+    const int B = m->cur_B;
+    const int Cl = m->E << 3, Ll = m->stages[3].H * m->stages[3].H;
+    // head: d(pooled) = dlogits Wc ; d(hfin)[b, t] = d(pooled)[b] / L ; LayerNorm backward
+    hipLaunchKernelGGL(cls_bwd_kernel, dim3(nblk((int64_t)B * Cl, 256, 1 << 30)), dim3(256), 0, s, m->dlogits, m->Wc, m->dpooled, B, m->C, Cl);
+    hipLaunchKernelGGL(mean_pool_bwd_kernel, dim3(nblk((int64_t)B * Ll * Cl, 256, 1 << 30)), dim3(256), 0, s, m->dpooled, m->h, B, Ll, Cl);
+    float *gcur = m->g0, *gnext = m->g1;
+    k_ln_bwd_f32(m->h, m->xlast, m->fmean, m->frstd, m->fg, nullptr, gcur, B * Ll, Cl, s);
+    for (int i = 3; i >= 0; --i) {
+        SStage& st = m->stages[i];
+        const int Cs = st.C, Hs = st.H, M = B * Hs * Hs;
+        const int nW = (Hs / WS) * (Hs / WS);
+        if (i < 3) {
+            // gcur = gradient w.r.t. the next stage's input [M/4, 2C]: reduction dgrad, LayerNorm backward, un-merge
+            k_gemm_f32(gm(gcur, 2 * Cs, st.Wred, 4 * Cs, 1, M / 4, 4 * Cs, 2 * Cs, m->dbig, 4 * Cs), s);
+            k_ln_bwd_f32(m->dbig, st.mg, st.mmean, st.mrstd, st.mg_g, nullptr, m->h, M / 4, 4 * Cs, s);
+            hipLaunchKernelGGL(merge_gather_kernel, dim3(nblk((int64_t)M * Cs, 256, 8192)), dim3(256), 0, s, m->h, gcur, B, Hs, Hs, Cs, 1);
+        }
+        for (int bi = st.depth - 1; bi >= 0; --bi) {
+            SBlock& bk = st.blocks[bi];
+            const int shift = (bi & 1) && Hs > WS ? WS / 2 : 0;
+            lin_dgrad(m, bk.fc2, gcur, M, m->dbig, s);                                   // d(a)
+            k_gelu_bwd_f32(m->dbig, bk.z, (int64_t)M * 4 * Cs, s);                       // d(z)
+            lin_dgrad(m, bk.fc1, m->dbig, M, m->h, s);
+            k_ln_bwd_f32(m->h, bk.xb, bk.mean2, bk.rstd2, bk.ln2_g, gcur, gnext, M, Cs, s);
+            lin_dgrad(m, bk.o, gnext, M, m->a, s);                                       // d(ctx)
+            hipLaunchKernelGGL(win_attn_bwd_kernel, dim3(nblk((int64_t)B * nW * st.heads, 2, 1 << 30)), dim3(128), 0, s, bk.qkvbuf,
+                               bk.table, bk.ctx, m->a, bk.lse, m->dqkv, B, Hs, Hs, Cs, st.heads, shift);
+            lin_dgrad(m, bk.qkv, m->dqkv, M, m->h, s);
+            k_ln_bwd_f32(m->h, bk.xa, bk.mean1, bk.rstd1, bk.ln1_g, gnext, gcur, M, Cs, s);
+        }
+    }
+    if (grad_x) {
+        const int L0 = m->G0 * m->G0, PK = 3 * m->P * m->P;
+        k_ln_bwd_f32(gcur, m->emb, m->emean, m->erstd, m->eg, nullptr, gnext, B * L0, m->E, s);
+        k_gemm_f32(gm(gnext, m->E, m->Wpe, PK, 1, B * L0, PK, m->E, m->patches, PK), s);
+        float is[3];
+        for (int c = 0; c < 3; ++c) is[c] = m->cur_norm ? 1.f / m->stdv[c] : 1.f;
+        k_patch_scatter_f32(m->patches, grad_x, B, m->S, m->P, is, s);
+    }
+    return VL_OK;
+}
+
+static int swin_check(vl_swin* m) {
+    if (m->err_flag && *m->err_flag) { *m->err_flag = 0; return vl_fail(VL_ERR_ARG, "a label passed to an earlier call was outside [0, num_labels)"); }
+    return VL_OK;
+}
+static int swin_launch_ok(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return vl_fail(VL_ERR_HIP, "%s: kernel launch failed: %s", what, hipGetErrorString(e));
+    return VL_OK;
+}
+
+int vl_swin_forward(vl_swin* m, const float* x, int batch, int normalise, float* logits_out, void* stream) {
+    if (!m || !x) return vl_fail(VL_ERR_ARG, "null argument");
+    if (m->max_batch <= 0) return vl_fail(VL_ERR_STATE, "no workspace: call vl_swin_plan + vl_swin_set_workspace first");
+    int rc = swin_check(m);
+    if (rc) return rc;
+    if ((rc = swin_forward(m, x, batch, normalise, (hipStream_t)stream))) return rc;
+    if (logits_out) HIPCHK(hipMemcpyAsync(logits_out, m->logits, (size_t)batch * m->C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return swin_launch_ok("vl_swin_forward");
+}
+
+int vl_swin_loss_ce(vl_swin* m, const int64_t* labels, float* loss_out, void* stream) {
+    if (!m || !labels) return vl_fail(VL_ERR_ARG, "null argument");
+    if (!m->cur_B) return vl_fail(VL_ERR_STATE, "vl_swin_loss_ce before vl_swin_forward");
+    k_ce_loss(m->logits, labels, m->cur_B, m->C, m->dlogits, m->loss_img, m->loss, m->err_flag, (hipStream_t)stream);
+    if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, m->loss, sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    m->have_loss = 1;
+    return VL_OK;
+}
+
+int vl_swin_backward_input(vl_swin* m, float* grad_x_out, void* stream) {
+    if (!m || !grad_x_out) return vl_fail(VL_ERR_ARG, "null argument");
+    int rc = swin_check(m);
+    if (rc) return rc;
+    if ((rc = swin_backward(m, grad_x_out, (hipStream_t)stream))) return rc;
+    return swin_launch_ok("vl_swin_backward_input");
+}
+
+int vl_swin_pgd_attack(vl_swin* m, const float* x0, const int64_t* labels, int batch, float eps, float alpha, int steps,
+                       int random_start, uint64_t seed, float* adv_out, void* stream) {
+    if (!m || !x0 || !labels || !adv_out) return vl_fail(VL_ERR_ARG, "bad argument");
+    if (m->max_batch <= 0 || batch <= 0 || batch > m->max_batch) return vl_fail(VL_ERR_STATE, "batch exceeds planned workspace");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = swin_check(m);
+    if (rc) return rc;
+    const int64_t n = (int64_t)batch * 3 * m->S * m->S;
+    HIPCHK(hipMemcpyAsync(m->stage_x0, x0, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(m->stage_labels, labels, (size_t)batch * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    if (random_start) k_pgd_init(m->stage_adv, m->stage_x0, eps, 0.f, 1.f, seed, n, s);
+    else HIPCHK(hipMemcpyAsync(m->stage_adv, m->stage_x0, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    for (int i = 0; i < steps; ++i) {
+        if ((rc = swin_forward(m, m->stage_adv, batch, 1, s))) return rc;
+        k_ce_loss(m->logits, m->stage_labels, batch, m->C, m->dlogits, m->loss_img, m->loss, m->err_flag, s);
+        m->have_loss = 1;
+        if ((rc = swin_backward(m, m->grad_img, s))) return rc;
+        k_pgd_step(m->stage_adv, m->stage_x0, m->grad_img, eps, alpha, 0.f, 1.f, n, s);
+    }
+    HIPCHK(hipMemcpyAsync(adv_out, m->stage_adv, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return swin_launch_ok("vl_swin_pgd_attack");
+}
+
+}  // extern "C"

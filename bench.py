@@ -131,7 +131,29 @@ def extras(P, syn, arch, args, dev, x, y):
         res["vit_l16_lora_r16_pgd"] = {"value": 128 / dtl, "unit": "img/s", "ms_per_step": 1e3 * dtl, "batch": 128,
                                        "tflops": 128 / dtl * args.pgd_steps * fl / 1e12}
         log(f"extras: ViT-L/16 + LoRA r=16 PGD-{args.pgd_steps} at batch 128: {128 / dtl:.1f} img/s")
-        del engl
+        # BASELINE config 5: adversarial-patch EoT steps (32x32 circular patch, random scale / rotation / location per image,
+        # Adam lr 5 on the patch) on the same model and batch: overlay -> forward -> CE -> backward-to-input -> patch gradient
+        patch_mod = importlib.import_module(PKG + ".patch")
+        model_mod = importlib.import_module(PKG + ".model")
+        vit = model_mod.ViTForImageClassification(archl, P.LoraSpec(r=16, alpha=16.0, dropout=0.0, targets=TARGETS), device=dev)
+        vit._eng = engl                     # the attack resolves its engine through the model object
+        atk = patch_mod.AdversarialPatchPyTorch(vit, rotation_max=22.5, scale_min=0.05, scale_max=1.0, learning_rate=5.0, max_iter=1,
+                                                batch_size=128, patch_shape=(3, 32, 32), patch_type="circle", targeted=False,
+                                                verbose=False, seed=3)
+        for _ in range(2):
+            atk.train_step(xl, yl)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ne = 5
+        for _ in range(ne):
+            atk.train_step(xl, yl)
+        torch.cuda.synchronize()
+        dte = (time.perf_counter() - t0) / ne
+        res["vit_l16_lora_r16_patch_eot_step"] = {"value": 128 / dte, "unit": "img/s", "ms_per_step": 1e3 * dte, "batch": 128,
+                                                  "tflops": 128 / dte * fl / 1e12,
+                                                  "what": "one EoT step: warp-and-paste 32x32 circle patch, forward, CE, backward to pixels, patch gradient, Adam, clamp"}
+        log(f"extras: ViT-L/16 patch EoT step {1e3 * dte:.1f} ms at batch 128")
+        del engl, vit, atk
         eng = None
     res["lora_train_step"] = {"value": bt / dt, "unit": "img/s", "ms_per_step": 1e3 * dt, "batch": bt,
                               "what": "forward(train, dropout 0.1) + CE + LoRA/classifier backward + Adam, clean inputs"}

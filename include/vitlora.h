@@ -196,6 +196,42 @@ int vl_patch_grad(const float* grad_out, const float* inv_affine, int batch, int
 /* x <- clamp(x, lo, hi): the patch is clipped to the classifier's clip_values after every optimiser step. */
 int vl_clamp(float* x, float lo, float hi, int64_t n, void* stream);
 
+/* ---- Swin Transformer + LoRA (BASELINE config 4: Swin-T + LoRA r = 16, PGD-40) -----------------------------------------
+ * The reference lists Swin-T (README.md:53) without code; the model is HF's SwinForImageClassification (modeling_swin.py):
+ * 4x4 patch embedding + LayerNorm, four stages of shifted-window attention blocks (window 7, relative position bias,
+ * -100 shift mask), patch merging between stages, final LayerNorm + mean pool + classifier.  fp32 on the exact-f32 MFMA.
+ * State-dict keys are HF-4.55.2 names ("swin.encoder.layers.S.blocks.B.attention.self.query.weight", ...).  LoRA adapters
+ * (eval mode: no dropout, no weight gradients on this path) on the VL_T_* targets; A / B live in one flat fp32 buffer. */
+typedef struct vl_swin_config {
+    int32_t image_size;   /* 224 */
+    int32_t patch_size;   /* 4   */
+    int32_t embed_dim;    /* 96  (stage i has embed_dim << i channels and heads[i] heads of dimension 32) */
+    int32_t depths[4];    /* 2, 2, 6, 2 */
+    int32_t heads[4];     /* 3, 6, 12, 24 */
+    int32_t window;       /* 7 */
+    int32_t num_labels;
+    float   ln_eps;       /* 1e-5 */
+    int32_t lora_r;       /* 0, 4, 8, 12 or 16 */
+    float   lora_alpha;
+    uint32_t lora_targets;
+    int32_t reserved[4];
+} vl_swin_config;
+typedef struct vl_swin vl_swin;
+int vl_swin_create(const vl_swin_config* cfg, vl_swin** out);
+int vl_swin_destroy(vl_swin* m);
+int vl_swin_load_tensor(vl_swin* m, const char* name, const float* src, int64_t numel, void* stream);
+int vl_swin_param_flat(vl_swin* m, float** ptr, int64_t* numel);
+/* which: 0 = lora_A [r, in], 1 = lora_B [out, r] of `target` in block `block` of stage `stage` */
+int vl_swin_param_tensor(vl_swin* m, int stage, int block, uint32_t target, int which, float** ptr, int64_t* numel);
+int vl_swin_set_normalization(vl_swin* m, const float mean[3], const float std[3]);
+int vl_swin_plan(vl_swin* m, int max_batch, size_t* bytes);
+int vl_swin_set_workspace(vl_swin* m, void* ws, size_t bytes);
+int vl_swin_forward(vl_swin* m, const float* x, int batch, int normalise, float* logits_out, void* stream);
+int vl_swin_loss_ce(vl_swin* m, const int64_t* labels, float* loss_out, void* stream);
+int vl_swin_backward_input(vl_swin* m, float* grad_x_out, void* stream);
+int vl_swin_pgd_attack(vl_swin* m, const float* x0, const int64_t* labels, int batch, float eps, float alpha, int steps,
+                       int random_start, uint64_t seed, float* adv_out, void* stream);
+
 /* Per-launch timing with HIP events on the launch stream, for bench.py's roofline object.
  * Between begin and report every kernel launch of this library is bracketed by an event
  * pair (PGD runs eagerly, not as a graph, while active).  report synchronises the device and

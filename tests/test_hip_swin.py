@@ -1,0 +1,134 @@
+"""Swin-T + LoRA on the vl_swin_* path (BASELINE config 4) against HF's SwinForImageClassification built from a local
+SwinConfig (random init; no reference code exists for this model -- SURVEY 8c names this class as the oracle).  fp32 path:
+held to 1e-4 (north_star allows 1e-3).  LoRA = plain-torch low-rank branches around HF's own nn.Linear modules (G5 style)."""
+import importlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import O, PKG, pkg, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+MEAN = torch.tensor(O.IMAGENET_MEAN).view(1, 3, 1, 1)
+STD = torch.tensor(O.IMAGENET_STD).view(1, 3, 1, 1)
+TARGETS = ("q", "k", "v", "o", "fc2")
+HF_ATTR = {"q": ("attention", "q_proj"), "k": ("attention", "k_proj"), "v": ("attention", "v_proj"), "o": ("attention", "o_proj"),
+           "fc1": ("mlp", "fc1"), "fc2": ("mlp", "fc2")}
+
+
+class LoraLinear(torch.nn.Module):
+    def __init__(self, base, A, B, scaling):
+        super().__init__()
+        self.base, self.A, self.B, self.scaling = base, A, B, scaling
+
+    def forward(self, x):
+        return self.base(x) + self.scaling * F.linear(F.linear(x, self.A), self.B)
+
+
+def hf_swin(num_labels, seed, depths=(2, 2, 6, 2)):
+    from transformers import SwinConfig, SwinForImageClassification
+    torch.manual_seed(seed)
+    cfg = SwinConfig(num_labels=num_labels, depths=list(depths))
+    cfg._attn_implementation = "eager"
+    m = SwinForImageClassification(cfg).eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():                                   # HF initialises bias tables / LayerNorms trivially: make every term count
+        for n, p in m.named_parameters():
+            if "relative_position_bias_table" in n:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+            elif n.endswith("norm.weight") or "layernorm" in n and n.endswith("weight"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            elif n.endswith("bias"):
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+            elif p.dim() >= 2:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    return m
+
+
+def add_lora(m, r, alpha, seed):
+    g = torch.Generator().manual_seed(seed)
+    ab = {}
+    for si, stage in enumerate(m.swin.encoder.layers):
+        for bi, blk in enumerate(stage.blocks):
+            for t in TARGETS:
+                parent = getattr(blk, HF_ATTR[t][0])
+                base = getattr(parent, HF_ATTR[t][1])
+                A = (torch.rand(r, base.in_features, generator=g) * 2 - 1) / base.in_features ** 0.5
+                B = torch.randn(base.out_features, r, generator=g) * 0.05
+                setattr(parent, HF_ATTR[t][1], LoraLinear(base, A, B, alpha / r))
+                ab[(si, bi, t)] = (A, B)
+    return ab
+
+
+def make_engine(m, num_labels, r=0, ab=None, depths=(2, 2, 6, 2)):
+    swin = importlib.import_module(PKG + ".swin")
+    eng = swin.SwinEngine(swin.SwinArch(num_labels=num_labels, depths=tuple(depths)), lora_r=r, lora_alpha=16.0, lora_targets=TARGETS if r else ())
+    sd = {k.replace(".base.", "."): v for k, v in m.state_dict().items() if not k.endswith((".A", ".B"))}
+    eng.load_state_dict(sd)
+    if ab:
+        for (si, bi, t), (A, B) in ab.items():
+            eng.param(si, bi, t, "A").copy_(A)
+            eng.param(si, bi, t, "B").copy_(B)
+    return eng
+
+
+@pytest.mark.parametrize("r", [0, 16])
+def test_swin_t_logits_loss_and_input_gradient(r):
+    torch.set_num_threads(16)
+    m = hf_swin(10, seed=3)
+    ab = add_lora(m, r, 16.0, seed=5) if r else None
+    eng = make_engine(m, 10, r, ab)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(3, 3, 224, 224, generator=g)
+    y = torch.randint(0, 10, (3,), generator=g)
+    logits = eng.forward(x.cuda(), normalise=True).cpu()
+    loss = eng.loss_ce(y.cuda()).item()
+    gx = eng.backward_input(tuple(x.shape)).cpu()
+    xr = x.clone().requires_grad_(True)
+    ref_logits = m((xr - MEAN) / STD).logits
+    ref_loss = F.cross_entropy(ref_logits, y)
+    (g_ref,) = torch.autograd.grad(ref_loss, xr)
+    assert rel_l2(logits, ref_logits.detach()) < 1e-4, rel_l2(logits, ref_logits.detach())
+    assert abs(loss - ref_loss.item()) < 1e-4 * ref_loss.item()
+    assert rel_l2(gx, g_ref) < 1e-4, rel_l2(gx, g_ref)
+    if r:       # the adapters matter in this case
+        eng0 = make_engine(m, 10, 0, None)
+        assert rel_l2(eng0.forward(x.cuda(), normalise=True).cpu(), ref_logits.detach()) > 1e-2
+
+
+def test_swin_shallow_variant_and_pgd_matches_torch_loop():
+    """depths (1, 1, 2, 1): odd / even block positions, shifted and unshifted windows in every stage that has them; PGD-3 of
+    vl_swin_pgd_attack against the same loop written with torch autograd on the HF model (canonical PGD)."""
+    torch.set_num_threads(16)
+    depths = (1, 2, 2, 1)
+    m = hf_swin(12, seed=13, depths=depths)
+    ab = add_lora(m, 8, 16.0, seed=15)
+    eng = make_engine(m, 12, 8, ab, depths=depths)
+    g = torch.Generator().manual_seed(19)
+    x = torch.rand(2, 3, 224, 224, generator=g)
+    y = torch.randint(0, 12, (2,), generator=g)
+    eps, alpha, steps = 8 / 255, 2 / 255, 3
+    adv = eng.pgd_attack(x.cuda(), y.cuda(), eps, alpha, steps, random_start=False).cpu()
+    ref = x.clone()
+    for _ in range(steps):
+        xr = ref.clone().requires_grad_(True)
+        (gr,) = torch.autograd.grad(F.cross_entropy(m((xr - MEAN) / STD).logits, y), xr)
+        ref = O.pgd_step(ref, x, gr, eps, alpha)
+    same = ((adv - ref).abs() < 1e-6).float().mean().item()
+    assert same > 0.999, same
+    assert (adv - x).abs().max().item() <= eps + 1e-6 and adv.min().item() >= 0 and adv.max().item() <= 1
+    # seeded random start, determinism
+    a1 = eng.pgd_attack(x.cuda(), y.cuda(), eps, alpha, 2, random_start=True, seed=4)
+    a2 = eng.pgd_attack(x.cuda(), y.cuda(), eps, alpha, 2, random_start=True, seed=4)
+    assert torch.equal(a1, a2)
+
+
+def test_swin_refuses_unsupported_shapes():
+    P = pkg()
+    swin = importlib.import_module(PKG + ".swin")
+    with pytest.raises(P.VitLoraError):
+        swin.SwinEngine(swin.SwinArch(image_size=200))              # 50 x 50 tokens: not a multiple of the window
+    with pytest.raises(P.VitLoraError):
+        swin.SwinEngine(swin.SwinArch(heads=(4, 6, 12, 24)))        # head_dim != 32
