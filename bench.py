@@ -155,6 +155,32 @@ def extras(P, syn, arch, args, dev, x, y):
         log(f"extras: ViT-L/16 patch EoT step {1e3 * dte:.1f} ms at batch 128")
         del engl, vit, atk
         eng = None
+    if args.swin:
+        # BASELINE config 4: Swin-T + LoRA r = 16, PGD (fp32 first form of the windowed-attention path), batch 256
+        swin = importlib.import_module(PKG + ".swin")
+        se = swin.SwinEngine(swin.SwinArch(num_labels=21), lora_r=16, lora_alpha=16.0, lora_targets=TARGETS, device=dev)
+        g = torch.Generator().manual_seed(5)
+        from transformers import SwinConfig, SwinForImageClassification     # random-init weights of the architecture (no hub access)
+        torch.manual_seed(0)
+        hf = SwinForImageClassification(SwinConfig(num_labels=21))
+        se.load_state_dict(hf.state_dict())
+        for si, d in enumerate((2, 2, 6, 2)):
+            for bi in range(d):
+                for t in TARGETS:
+                    A, Bm = se.param(si, bi, t, "A"), se.param(si, bi, t, "B")
+                    A.copy_((torch.rand(A.shape, generator=g) * 2 - 1) / A.shape[1] ** 0.5)
+                    Bm.copy_(torch.randn(Bm.shape, generator=g) * 0.02)
+        nsw = 4
+        se.pgd_attack(x, y, EPS, ALPHA, 1, random_start=True, seed=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        se.pgd_attack(x, y, EPS, ALPHA, nsw, random_start=True, seed=2)
+        torch.cuda.synchronize()
+        dts = (time.perf_counter() - t0) / nsw
+        res["swin_t_lora_r16_pgd_step_f32"] = {"value": x.shape[0] / dts, "unit": "img/s per PGD step", "ms_per_pgd_step": 1e3 * dts,
+                                               "batch": int(x.shape[0]), "pgd40_img_per_s": x.shape[0] / (40 * dts), "dtype": "f32"}
+        log(f"extras: Swin-T + LoRA r=16 PGD step {1e3 * dts:.1f} ms at batch {x.shape[0]} (fp32)")
+        del se, hf
     res["lora_train_step"] = {"value": bt / dt, "unit": "img/s", "ms_per_step": 1e3 * dt, "batch": bt,
                               "what": "forward(train, dropout 0.1) + CE + LoRA/classifier backward + Adam, clean inputs"}
     log(f"extras: LoRA train step {1e3 * dt:.2f} ms at batch {bt}")
@@ -211,6 +237,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--vitl", action="store_true", help="extras: also time the attack on ViT-L/16 + LoRA r=16 at batch 128")
+    ap.add_argument("--swin", action="store_true", help="extras: also time a PGD step of the Swin-T + LoRA r=16 path (fp32) at the bench batch")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (merged-LoRA attack, LoRA train step)")
     args = ap.parse_args()
 
