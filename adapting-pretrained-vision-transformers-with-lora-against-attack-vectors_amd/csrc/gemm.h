@@ -38,6 +38,9 @@ struct GemmArgs {
     int n_algo, k2_algo;
     int k2_used;          // nonzero columns of the LoRA K tile (r * modules); <= 32 lets the 256-row kernel skip its upper half
 
+    // gemm_pp only (gemm_pp_fuses_down): LoRA down projection t = A1 down_W^T computed inside the GEMM; down_W = [16 * groups
+    // rows][K1] h16 (the rows of Ad in use, zero padded), down_out (optional) receives t (ld = down_ld); A2 is then unused
+    const h16* down_W; int down_ldw; h16* down_out; int down_ld; int down_groups;
     int dephase;      // gemm256: start offset unit (x 8128 cycles x (workgroup/8 mod 4)); 0 = off
     // EPI_DROP_ACC: dropout mask of element (m, n) of the module input = drop_scale(seed, stream, m*N + n)
     const h16* G; int ldg;          // optional extra factor (gelu'(z) for the fc2 input gradient)
@@ -46,4 +49,8 @@ struct GemmArgs {
 
 // bn = 128 (default) or 64 (skinny LoRA-down GEMMs)
 void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s);
-int gemm_init(int device);   // per-device kernel attributes (outside any stream capture); 0 = ok
+int gemm_init(int device);
+int gemm_force_small(int v);   // 1: every GEMM on the 128-row kernel (self-check reference); returns the previous setting
+int gemm_pp_mode();           // gemm_pp.hip: 0 = off, 1 = every supported shape, 2 = epilogue-heavy shapes only
+void gemm_pp_set_mode(int m);
+bool gemm_pp_fuses_down(const GemmArgs& a, int epi);   // a.down_* set: can launch_gemm run this GEMM with the down projection inside?   // per-device kernel attributes (outside any stream capture); 0 = ok

@@ -17,6 +17,9 @@
 void launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);   // gemm256.hip
 bool gemm256_supports(const GemmArgs& a, int epi);
 int gemm256_init();
+void launch_gemm_pp(const GemmArgs& a, int epi, hipStream_t s);    // gemm_pp.hip
+bool gemm_pp_supports(const GemmArgs& a, int epi);
+int gemm_pp_init();
 
 namespace {
 
@@ -185,6 +188,7 @@ int gemm_init(int device) {
     set_attr<128, EPI_STORE_F32>();
     set_attr<128, EPI_DROP_ACC>();
     if (int e2 = gemm256_init()) g_attr_err = e2;
+    if (int e3 = gemm_pp_init()) g_attr_err = e3;
     const char* e = getenv("VITLORA_GEMM128");      // A/B switch: force the 128-row kernel
     g_force_small = (e && e[0] == '1') ? 1 : 0;
     const char* dp = getenv("VITLORA_DEPHASE");      // experiment knob: start-offset unit of gemm256
@@ -194,10 +198,18 @@ int gemm_init(int device) {
     return 0;
 }
 
+int gemm_force_small(int v) { const int old = g_force_small; g_force_small = v; return old; }
+
 void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
     const double mv = a.Mvalid ? a.Mvalid : a.M;
     const double flops = 2.0 * mv * (a.n_algo ? a.n_algo : a.N) * (a.K1 + (a.k2_algo ? a.k2_algo : a.K2));
     char name[64];
+    if (bn != 64 && g_force_small != 1 && gemm_pp_supports(a, epi)) {
+        GemmArgs b = a;
+        if (g_dephase >= 0) b.dephase = g_dephase;
+        launch_gemm_pp(b, epi, s);
+        return;
+    }
     if (bn != 64 && g_force_small != 1 && gemm256_supports(a, epi)) {
         GemmArgs b = a;
         if (g_dephase >= 0) b.dephase = g_dephase;

@@ -92,7 +92,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
     const int fr = lane & 15, fg = lane >> 4;
     const int lr = lane >> 3, lc = lane & 7;
     const unsigned csw = (unsigned)((lc ^ lr) * 8);   // swizzled source chunk (row & 7 == lr for every load group)
-    const unsigned wl = (unsigned)(16 * (lr >> 2) + (lr & 3));   // lane part of the permuted W row
+    // fp32 outputs keep the natural MFMA column order (a lane quad then writes 64 contiguous bytes per row and
+    // instruction); 16-bit outputs permute the W rows so that a lane owns 16 adjacent columns (16-byte pieces)
+    constexpr bool PERM = !(EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32);
+    const unsigned wl = PERM ? (unsigned)(16 * (lr >> 2) + (lr & 3)) : (unsigned)lr;   // lane part of the W row
     const int tilesN = p.N / BN;
     const int nk1 = p.K1 / BK;
     const int nk = nk1 + p.K2 / BK;
@@ -133,7 +136,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
             const int g = w * 2 + i;
             const int chunk = g >> 2, gi = g & 3;
             // LDS row (chunk, h, j' = gi>>1, r' = (gi&1)*8 + lr)  <-  column chunk*64 + 16*(r'>>2) + 4*(2h+j') + (r'&3)
-            const unsigned so = ((unsigned)(bn * BN + chunk * 64 + 4 * (2 * h + (gi >> 1)) + 32 * (gi & 1)) * ldw + k0) * 2u;
+            const unsigned col = PERM ? chunk * 64 + 4 * (2 * h + (gi >> 1)) + 32 * (gi & 1) : chunk * 64 + h * 32 + gi * 8;
+            const unsigned so = ((unsigned)(bn * BN) + col) * ldw * 2u + k0 * 2u;
             glds16(Wp + (size_t)(vo + so), dst + (chunk * 64 + h * 32 + gi * 8) * BK);
         }
     };
@@ -256,10 +260,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
         f32x4 bv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int n0 = bn * BN + wn * 64 + fg * 16;  // this lane's 16 adjacent columns
+        const int n0 = bn * BN + wn * 64 + fg * 16;  // this lane's 16 adjacent columns (PERM)
+        const int nq = bn * BN + wn * 64 + fg * 4;   // natural order: column tile j of this lane starts at nq + 16 j
         if (p.bias) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(p.bias + n0 + 4 * j);
+            for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(p.bias + (PERM ? n0 + 4 * j : nq + 16 * j));
         }
         if constexpr (EPI == EPI_GELU_BWD) {
             // the saved gelu'(z) of a whole half of the wave's rows is requested before any of it is used or any
@@ -287,7 +292,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
                 f32x4 v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = acc[i][j] + bv[j];
-                epilogue_row16<EPI>(p, m, n0, v);
+                if constexpr (PERM) {
+                    epilogue_row16<EPI>(p, m, n0, v);
+                } else {
+                    float* dst = (float*)p.C + (size_t)m * p.ldc + nq;
+                    if constexpr (EPI == EPI_RESID_F32) {
+                        const float* r = (const float*)p.R + (size_t)m * p.ldr + nq;
+                        f32x4 rv[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) rv[q] = *(const f32x4*)(r + 16 * q);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) *(f32x4*)(dst + 16 * q) = v[q] + rv[q];
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) *(f32x4*)(dst + 16 * q) = v[q];
+                    }
+                }
             }
         }
         GSTAMP(it_, 3);

@@ -113,8 +113,17 @@ void linear_fwd(vl_model* m, const Linear& ln, const h16* x, h16* t, int Mpad, G
         g.k2_algo = m->r;      // each output column sees r LoRA columns
         g.k2_used = ext_cols(m, ln);
         d.C = t; d.ldc = ln.kext;
-        if (!t_ready) launch_gemm(d, EPI_STORE_H16, 64, s);
         add_ext(g, t, ln.kext, ln.Bu, ln.kext, ln.kext);
+        // long-K projections (fc2: K = 3072, t would cost a pass over the whole GELU output): the ping-pong GEMM computes t
+        // itself from the A tiles it streams through LDS anyway (gemm_pp.hip, ND > 0) and still writes it out for wgrad
+        bool fused = false;
+        if (!t_ready && xb == x && ln.in >= 2048 && ln.kext == 64) {
+            GemmArgs f = g;
+            f.down_W = ln.Ad; f.down_ldw = ln.in; f.down_out = t; f.down_ld = ln.kext;
+            f.down_groups = ext_cols(m, ln) <= 16 ? 1 : ext_cols(m, ln) <= 32 ? 2 : 0;
+            if (f.down_groups && gemm_pp_fuses_down(f, epi)) { g = f; g.A2 = nullptr; fused = true; }
+        }
+        if (!t_ready && !fused) launch_gemm(d, EPI_STORE_H16, 64, s);
     }
     launch_gemm(g, epi, 128, s);
 }
@@ -602,10 +611,12 @@ static int forward_impl(vl_model* m, const float* x, int B, int normalise, int t
         memset(&g, 0, sizeof g); g.C = delta; g.ldc = D;
         if (re) { g.C = w.xs[2 * l + 1]; g.R = w.xs[2 * l]; g.ldr = D; }
         linear_fwd(m, ly.lin[LO], w.ctx[l], w.t[LO][l], Mpad, g, re ? EPI_RESID_F32 : EPI_STORE_H16, s, l * 4 + LO, t_o);
-        if (re) k_layernorm_fwd(w.xs[2 * l + 1], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D, m->cfg.ln_eps, nullptr, nullptr, nullptr, 0, nullptr, s);
-        else k_layernorm_fwd(w.xs[2 * l], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D, m->cfg.ln_eps, delta, w.xs[2 * l + 1], nullptr, 0, nullptr, s);
+        const int n2 = fused_down_fwd(m, ly.lin[LFC1]);      // t of fc1 (r columns) comes out of LN2
+        const h16* P2 = n2 ? ly.lin[LFC1].Ad : nullptr;
+        if (re) k_layernorm_fwd(w.xs[2 * l + 1], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D, m->cfg.ln_eps, nullptr, nullptr, P2, n2, w.t[LFC1][l], s);
+        else k_layernorm_fwd(w.xs[2 * l], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D, m->cfg.ln_eps, delta, w.xs[2 * l + 1], P2, n2, w.t[LFC1][l], s);
         memset(&g, 0, sizeof g); g.C = w.a[l]; g.ldc = m->MLP; g.C2 = w.z[l]; g.ldc2 = m->MLP;
-        linear_fwd(m, ly.lin[LFC1], w.h2[l], w.t[LFC1][l], Mpad, g, EPI_GELU, s, l * 4 + LFC1);
+        linear_fwd(m, ly.lin[LFC1], w.h2[l], w.t[LFC1][l], Mpad, g, EPI_GELU, s, l * 4 + LFC1, n2 > 0);
         memset(&g, 0, sizeof g); g.C = delta; g.ldc = D;
         if (re) { g.C = w.xs[2 * l + 2]; g.R = w.xs[2 * l + 1]; g.ldr = D; }
         linear_fwd(m, ly.lin[LFC2], w.a[l], w.t[LFC2][l], Mpad, g, re ? EPI_RESID_F32 : EPI_STORE_H16, s, l * 4 + LFC2);
@@ -948,6 +959,15 @@ int vl_bench_gemm(int M, int N, int K1, int K2, int epi, int bn, int iters, floa
     GemmArgs g = gemm_args(A, K1, W, K1, K1, M, N);
     if (K2) add_ext(g, A2, K2, W2, K2, K2);
     g.bias = bias; g.C = C; g.ldc = N; g.C2 = C2; g.ldc2 = N; g.R = R; g.ldr = N;
+    h16* Wd = nullptr;
+    if (epi == 200 || epi == 300) {        // store_h16 with the LoRA down projection (16 / 32 columns) inside the ping-pong kernel
+        const int nd = epi / 100 - 1;
+        epi = EPI_STORE_H16;
+        HIPCHK(hipMalloc(&Wd, (size_t)64 * K1 * 2 + 256));
+        k_fill_random_h16(Wd, (size_t)64 * K1, 7, 0);
+        g.A2 = nullptr; g.down_W = Wd; g.down_ldw = K1; g.down_out = A2; g.down_ld = 64; g.down_groups = nd;
+        if (!gemm_pp_fuses_down(g, epi)) return fail(VL_ERR_UNSUPPORTED, "shape not fusable");
+    }
     if (epi >= 100) { epi -= 100; g.ldc = 0; g.ldc2 = 0; }     // diagnostic: every row stored to row 0 (no HBM write stream)
     if (epi == EPI_RESID_F32) g.R = C;
     hipEvent_t e0, e1;
@@ -962,9 +982,88 @@ int vl_bench_gemm(int M, int N, int K1, int K2, int epi, int bn, int iters, floa
     *ms_out = ms / iters;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(A); (void)hipFree(W); (void)hipFree(A2); (void)hipFree(W2); (void)hipFree(C); (void)hipFree(C2);
-    (void)hipFree(R); (void)hipFree(bias);
+    (void)hipFree(R); (void)hipFree(bias); (void)hipFree(Wd);
     return VL_OK;
 }
+
+// ---- GEMM self-check (tests/test_hip_engine.py): the same random GEMM through the 128-row kernel (the oldest, simplest
+// form) and through whichever kernel launch_gemm selects for `pp_mode`; returns the largest |difference| over C (and C2) --
+int vl_check_gemm(int M, int N, int K1, int K2, int epi, int pp_mode, float* max_diff) {
+    if (M % 128 || N % 256 || K1 % 64 || K2 % 64 || !max_diff || pp_mode < 0 || pp_mode > 3) return fail(VL_ERR_ARG, "bad argument");
+    const int nd = pp_mode >= 2 ? pp_mode - 1 : 0;           // fused LoRA down projection with 16 nd columns
+    if (nd && (K2 != 64 || epi != EPI_STORE_H16)) return fail(VL_ERR_ARG, "fused down: K2 = 64, epi = store_h16");
+    { int dev = 0; HIPCHK(hipGetDevice(&dev)); if (gemm_init(dev)) return fail(VL_ERR_HIP, "gemm_init failed"); }
+    h16 *A = nullptr, *W = nullptr, *A2 = nullptr, *W2 = nullptr, *Wd = nullptr, *T2 = nullptr;
+    float *R = nullptr, *bias = nullptr;
+    char *C[2] = {nullptr, nullptr}, *C2[2] = {nullptr, nullptr};
+    const size_t nA = (size_t)M * K1, nW = (size_t)N * K1, nC = (size_t)M * N;
+    HIPCHK(hipMalloc(&A, nA * 2)); HIPCHK(hipMalloc(&W, nW * 2));
+    HIPCHK(hipMalloc(&A2, (size_t)M * 64 * 2 + 256)); HIPCHK(hipMalloc(&W2, (size_t)N * 64 * 2 + 256));
+    HIPCHK(hipMalloc(&T2, (size_t)M * 64 * 2 + 256)); HIPCHK(hipMalloc(&Wd, (size_t)64 * K1 * 2 + 256));
+    HIPCHK(hipMalloc(&R, nC * 4)); HIPCHK(hipMalloc(&bias, (size_t)N * 4));
+    for (int i = 0; i < 2; ++i) { HIPCHK(hipMalloc(&C[i], nC * 4)); HIPCHK(hipMalloc(&C2[i], nC * 2)); }
+    k_fill_random_h16(A, nA, 1, 0); k_fill_random_h16(W, nW, 2, 0);
+    k_fill_random_h16(A2, (size_t)M * 64, 3, 0); k_fill_random_h16(W2, (size_t)N * 64, 4, 0);
+    k_fill_random_h16((h16*)R, nC * 2, 5, 0); k_fill_random_h16((h16*)bias, (size_t)N * 2, 6, 0);
+    HIPCHK(hipMemset(Wd, 0, (size_t)64 * K1 * 2)); HIPCHK(hipMemset(T2, 0, (size_t)M * 64 * 2));
+    if (nd) {
+        k_fill_random_h16(Wd, (size_t)(16 * nd - 8) * K1, 7, 0);          // 8 / 24 rows in use, like r = 8 on one / three modules
+        GemmArgs d = gemm_args(A, K1, Wd, K1, K1, M, 64);                   // reference t through the skinny GEMM
+        d.C = A2; d.ldc = 64;
+        launch_gemm(d, EPI_STORE_H16, 64, 0);
+    }
+    const int keep = gemm_pp_mode();
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipMemset(C[i], 0, nC * 4)); HIPCHK(hipMemset(C2[i], 0, nC * 2));
+        GemmArgs g = gemm_args(A, K1, W, K1, K1, M, N);
+        if (K2) add_ext(g, A2, K2, W2, K2, K2);
+        g.bias = bias; g.C = C[i]; g.ldc = N; g.C2 = C2[i]; g.ldc2 = N; g.R = R; g.ldr = N;
+        if (epi == EPI_RESID_F32) { HIPCHK(hipMemcpy(C[i], R, nC * 4, hipMemcpyDeviceToDevice)); g.R = C[i]; }
+        gemm_pp_set_mode(i == 0 ? 0 : (pp_mode ? 1 : 0));
+        if (i == 1 && nd) {
+            g.A2 = nullptr; g.down_W = Wd; g.down_ldw = K1; g.down_out = T2; g.down_ld = 64; g.down_groups = nd;
+            if (!gemm_pp_fuses_down(g, epi)) { gemm_pp_set_mode(keep); return fail(VL_ERR_UNSUPPORTED, "shape not fusable"); }
+        }
+        const int keep_small = gemm_force_small(i == 0 ? 1 : 0);
+        launch_gemm(g, epi, 128, 0);
+        gemm_force_small(keep_small);
+    }
+    gemm_pp_set_mode(keep);
+    HIPCHK(hipDeviceSynchronize());
+    const bool f32out = epi == EPI_RESID_F32 || epi == EPI_STORE_F32;
+    const size_t bytes = nC * (f32out ? 4 : 2);
+    std::vector<char> h0(bytes), h1(bytes);
+    HIPCHK(hipMemcpy(h0.data(), C[0], bytes, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h1.data(), C[1], bytes, hipMemcpyDeviceToHost));
+    double md = 0.0;
+    auto cmp = [&](const char* a, const char* b, bool f32, size_t n) {
+        for (size_t i = 0; i < n; ++i) {
+            const double x = f32 ? ((const float*)a)[i] : (double)(float)((const h16*)a)[i];
+            const double y = f32 ? ((const float*)b)[i] : (double)(float)((const h16*)b)[i];
+            const double d = x > y ? x - y : y - x;
+            if (!(d <= md)) md = d == d ? d : 1e30;
+        }
+    };
+    cmp(h0.data(), h1.data(), f32out, nC);
+    if (epi == EPI_GELU) {
+        HIPCHK(hipMemcpy(h0.data(), C2[0], nC * 2, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(h1.data(), C2[1], nC * 2, hipMemcpyDeviceToHost));
+        cmp(h0.data(), h1.data(), false, nC);
+    }
+    if (nd) {          // the t the fused kernel wrote against the skinny GEMM's
+        std::vector<char> t0((size_t)M * 64 * 2), t1((size_t)M * 64 * 2);
+        HIPCHK(hipMemcpy(t0.data(), A2, t0.size(), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(t1.data(), T2, t1.size(), hipMemcpyDeviceToHost));
+        cmp(t0.data(), t1.data(), false, (size_t)M * 64);
+    }
+    *max_diff = (float)md;
+    (void)hipFree(A); (void)hipFree(W); (void)hipFree(A2); (void)hipFree(W2); (void)hipFree(R); (void)hipFree(bias);
+    (void)hipFree(Wd); (void)hipFree(T2);
+    for (int i = 0; i < 2; ++i) { (void)hipFree(C[i]); (void)hipFree(C2[i]); }
+    return VL_OK;
+}
+
+int vl_debug_set_gemm_pp(int mode) { const int old = gemm_pp_mode(); gemm_pp_set_mode(mode); return old; }
 
 // ---- profiling -------------------------------------------------------------------------------
 int vl_profile_begin(void) {

@@ -244,6 +244,13 @@ int vl_profile_report(char* buf, size_t cap);
  * launches timed with HIP events; epi = GemmEpilogue of csrc/gemm.h (+100: all rows stored to row 0). */
 int vl_bench_gemm(int M, int N, int K1, int K2, int epi, int bn, int iters, float* ms_out);
 
+/* GEMM self-check: one random GEMM (M % 128 == 0, N % 256 == 0) through the 128-row kernel and through the kernel
+ * selected with pp_mode (0 = 256-row persistent kernel, 1 = ping-pong kernel, 2 / 3 = ping-pong kernel with the LoRA down
+ * projection of 16 / 32 columns computed inside it, checked against the separate skinny GEMM); *max_diff = largest |difference|. */
+int vl_check_gemm(int M, int N, int K1, int K2, int epi, int pp_mode, float* max_diff);
+/* A/B switch of the ping-pong GEMM (same values as the environment variable VITLORA_GEMM_PP); returns the old mode. */
+int vl_debug_set_gemm_pp(int mode);
+
 /* Introspection for tests / profiling.  vl_debug_counter: "graph_captures" = PGD graphs captured so far,
  * "commits" = vl_lora_commit executions, "dirty" = 1 if parameters changed since the last commit. */
 int vl_debug_counter(vl_model* m, const char* what, int64_t* value);

@@ -346,3 +346,23 @@ def test_per_image_attention_kernels_with_fused_lora_down(image_size, batch, r, 
     eng2.loss_ce(y.cuda())
     gx2, _ = eng2.backward(True, False, tuple(x.shape))
     assert rel_l2(logits, logits2) < 5e-4 and rel_l2(gx.cpu(), gx2.cpu()) < 1e-3
+
+
+@pytest.mark.parametrize("shape", [(128 * 50, 3072, 768, 64), (128 * 100, 768, 3072, 64), (128 * 110, 3072, 768, 0),
+                                   (128 * 3, 768, 768, 64), (128 * 37, 2304, 768, 64)])
+def test_main_gemm_kernels_agree_bitwise(shape):
+    """The three forms of the main GEMM on the same random operands: the persistent 256-row kernel (pp_mode 0) and the
+    ping-pong kernel (pp_mode 1: epilogue of one tile under the main loop of the next) against the plain 128-row kernel.
+    Same MFMA, same K order: the results must be IDENTICAL for the store / residual / gelu' epilogues; the GELU forward
+    may differ by one fp16 ulp of its largest outputs (16-column and 4-column forms of the same epilogue, contracted differently).  The sizes
+    cover full pair rounds, a single-tile tail round, a pair tail round, one tile per workgroup, and N = 9 tiles."""
+    import ctypes as C
+    import importlib
+    from helpers import PKG
+    lib = importlib.import_module(PKG + "._lib").load()
+    M, N, K1, K2 = shape
+    for epi, name in ((0, "store_h16"), (1, "resid_f32"), (2, "gelu"), (3, "gelu_bwd"), (6, "store_f32")):
+        for mode in (0, 1):
+            d = C.c_float(-1.0)
+            assert lib.vl_check_gemm(M, N, K1, K2, epi, mode, C.byref(d)) == 0, lib.vl_last_error()
+            assert d.value <= (4e-3 if epi == 2 else 0.0), (name, mode, d.value)

@@ -204,3 +204,19 @@ def test_data_parallel_gradient_exchange_gloo(tmp_path):
              for r in range(2)]
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+def test_pingpong_gemm_builds_without_vgpr_spills():
+    """csrc/gemm_pp.hip keeps explicitly loaded operands in registers across steps (asm global_load + counted vmcnt): a
+    spilled or copied destination register would be saved before its data arrives, so the build must not spill VGPRs."""
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    src = os.path.join(ROOT, PKG, "csrc", "gemm_pp.hip")
+    out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-c", src,
+                          "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    spills = [int(x) for x in re.findall(r"VGPRs Spill: (\d+)", out.stderr)]
+    assert len(spills) >= 5 and all(v == 0 for v in spills), spills
