@@ -30,6 +30,17 @@ __device__ unsigned long long g_attn_stamps[8192 * 8 * 8];
 #define ISTAMP(hd, k) do { } while (0)
 #endif
 
+// Workgroup barrier that orders LDS only.  __syncthreads() also drains every wave's GLOBAL loads and stores
+// (s_waitcnt vmcnt(0)) -- in the per-image kernels that made each head wait out its own output stores and the prefetch of
+// the next head's operands twice (a quarter of the backward: tools/attn_img_stamp.hip).  Nothing in those kernels is
+// exchanged between waves through global memory; the loader wave waits for its LDS-DMA itself before it arrives.
+#define LDS_BARRIER()                                                        \
+    do {                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+    } while (0)
+
 namespace {
 
 constexpr int HD = 64;
@@ -550,13 +561,18 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_fwd_img_kernel(const h16*
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-            auto step = [&](int kt, auto masked) {
-                constexpr bool MASKED = decltype(masked)::value;
+            // software pipeline over the key tiles: the S MFMAs of tile kt+1 are issued before the softmax VALU of tile kt
+            // (independent registers), so one wave keeps both the matrix pipe and the VALU busy
+            auto scores = [&](int kt) {
                 f32x16 s;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) s = mfma32(row_frag_o(sK, kt, fo.row[ks]), qf[ks], s);
+                return s;
+            };
+            auto step = [&](int kt, f32x16 s, auto masked) {
+                constexpr bool MASKED = decltype(masked)::value;
                 float tmax = -INFINITY;
                 if constexpr (MASKED) {
 #pragma unroll
@@ -589,9 +605,77 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_fwd_img_kernel(const h16*
                 }
             };
             const int nfull = T >> 5;
+            const int ntile = nfull + ((T & 31) ? 1 : 0);
+            if (ntile == NT) {
+                // every key tile in use (T = 197: the path's case): whole score rows in registers (16 NT values per lane),
+                // ONE row maximum, no running rescale, and a branch-free body the scheduler can interleave -- the exp2 of
+                // tile kt+1 issues under the P V MFMAs of tile kt
+                f32x16 S[NT];
+                {
+                    // K row fragments one tile ahead of the MFMAs that use them (the compiler otherwise reloads one
+                    // register quad per MFMA and waits out the LDS latency 4 NT times)
+                    h16x8 kf[2][4];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) kf[0][ks] = row_frag_o(sK, 0, fo.row[ks]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kt = 0; kt < NT; ++kt) {
+                        if (kt + 1 < NT) {
+#pragma unroll
+                            for (int ks = 0; ks < 4; ++ks) kf[(kt + 1) & 1][ks] = row_frag_o(sK, kt + 1, fo.row[ks]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) S[kt][r] = 0.f;
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) S[kt] = mfma32(kf[kt & 1][ks], qf[ks], S[kt]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (T & 31) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (((NT - 1) * 32 + (r & 3) + 8 * (r >> 2)) >= tcut) S[NT - 1][r] = -INFINITY;
+                }
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, S[kt][r]);
+                m = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float mc = -m * scale_log2e;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+                    // this tile's V fragments are requested before its exp2 block and consumed after it
+                    h16x8 vfr[2][2];
+#pragma unroll
+                    for (int st = 0; st < 2; ++st)
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) vfr[st][dt] = tr_frag_o(sV, kt, st, fo.tr[dt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    float ps = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { S[kt][r] = fexp2(fmaf(S[kt][r], scale_log2e, mc)); ps += S[kt][r]; }
+                    l += ps;
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        const h16x8 pb = pack8(S[kt], st);
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(vfr[st][dt], pb, o[dt]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                f32x16 s_cur = scores(0);
 #pragma unroll 1
-            for (int kt = 0; kt < nfull; ++kt) step(kt, std::false_type{});
-            if (T & 31) step(nfull, std::true_type{});
+                for (int kt = 0; kt < nfull; ++kt) {
+                    f32x16 s_nxt = s_cur;
+                    if (kt + 1 < ntile) s_nxt = scores(kt + 1);
+                    step(kt, s_cur, std::false_type{});
+                    s_cur = s_nxt;
+                }
+                if (T & 31) step(nfull, s_cur, std::true_type{});
+            }
             if (hd + 1 < H) {                                  // next head's query fragments fly under the epilogue
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const h16x8*)(base + (size_t)qc * ld + (hd + 1) * HD + 8 * h + 16 * ks);
@@ -618,7 +702,7 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_fwd_img_kernel(const h16*
             }
             if (q < T && h == 0) lse2[((size_t)b * H + hd) * T + q] = m * scale_log2e + log2f(l);
         }
-        __syncthreads();
+        LDS_BARRIER();
     }
     if (lo.W && !loader && active && q < T && 4 * h < lo.r) {
         const f32x4 t4 = *(const f32x4*)(tsum + q * 8 + 4 * h);      // LoRA columns 4h .. 4h+3 of this token
@@ -778,7 +862,7 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_bwd_img_kernel(const h16*
             store_rows32_half(wimg + w * 2048, dq, 1.f, dqkv + (size_t)b * T * ld + hd * HD, ld, w * 32, T, lane);
         }
         ISTAMP(hd, 2);
-        __syncthreads();
+        LDS_BARRIER();
         ISTAMP(hd, 3);
         // ------------------------------ phase B: dK, dV (key on the lane; Q, dO images) ------------------------------
         if (loader) {
@@ -848,12 +932,13 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_bwd_img_kernel(const h16*
             }
             store_rows32_half(wimg + w * 2048, dk, 1.f, dqkv + (size_t)b * T * ld + D + hd * HD, ld, w * 32, T, lane);
             store_rows32_half(wimg + w * 2048, dv, 1.f, dqkv + (size_t)b * T * ld + 2 * D + hd * HD, ld, w * 32, T, lane);
+            ISTAMP(hd, 7);
             // next head's phase A operands (q, dO, O rows of the own block, LSE): the registers are free now and the
             // latency overlaps the wait at the barrier
             if (hd + 1 < H) fetch_a(hd + 1);
         }
         ISTAMP(hd, 5);
-        __syncthreads();
+        LDS_BARRIER();
         ISTAMP(hd, 6);
     }
     if (lo.W && !loader && active && tok < T && 4 * h < lo.r) {

@@ -112,6 +112,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
     constexpr bool PERM = EPI != EPI_STORE_F32;
     const unsigned wl = PERM ? (unsigned)(16 * (lr >> 2) + (lr & 3)) : (unsigned)lr;      // lane part of the W row
     const int tilesN = p.N / BN;
+    // tile id -> (bm, bn): groups of GM tile rows are walked column by column (bm fastest inside a group), so that the 32
+    // workgroups of an XCD, which hold consecutive ids, cover a compact block (16 row panels x 2-4 W panels fits the 4 MB L2)
+    // and the two tiles of a pair share their W panel.  Row-major order re-read the operands 3x from HBM (rocprofv3 FETCH_SIZE).
+    constexpr int GM = 16;
+    const int tilesM = ntiles / tilesN;
+    auto bm_of = [&](int tile, int& bn) -> int {
+        const int per_group = GM * tilesN;
+        const int g = tile / per_group, r = tile - g * per_group;
+        const int rows = min(GM, tilesM - g * GM);
+        bn = r / rows;
+        return g * GM + (r - bn * rows);
+    };
     const int nk1 = p.K1 / BK;
     const int nk = nk1 + p.K2 / BK;
     const int G = gridDim.x, bid = (int)blockIdx.x;
@@ -126,7 +138,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
     // address = wave-uniform 64-bit base (SGPRs) + kernel-invariant 32-bit per-lane offset
     auto issue_ktile = [&](auto main_only, int tile, int T, int stage) {
         constexpr bool MAIN = decltype(main_only)::value != 0;
-        const int bm = tile / tilesN, bn = tile - bm * tilesN;
+        int bn; const int bm = bm_of(tile, bn);
         const bool ext = !MAIN && T >= nk1;
         const char* Ap = (const char*)(ext ? p.A2 : p.A1);
         const char* Wp = (const char*)(ext ? p.W2 : p.W1);
@@ -229,7 +241,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
     f32x4 bv[4];                      // bias of the lane's 16 columns
     f32x4 pre[3][4];                  // operands requested ahead (gelu' of GELU_BWD), ring of 3 row blocks
     auto request_bias = [&](int tile) {
-        const int bn = tile % tilesN;
+        int bn; (void)bm_of(tile, bn);
         const int n0 = PERM ? bn * BN + wn * 64 + fg * 16 : bn * BN + wn * 64 + fg * 4;
         const float* bp = p.bias ? p.bias + n0 : (const float*)p.A1;      // always 4 loads (static vmcnt counts)
 #pragma unroll
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
     };
     auto request_block = [&](int tile, auto cc) {
         constexpr int c = decltype(cc)::value;
-        const int bm = tile / tilesN, bn = tile - bm * tilesN;
+        int bn; const int bm = bm_of(tile, bn);
         const int m = bm * BM + c * 16 + fr, n0 = bn * BN + wn * 64 + fg * 16;
         if constexpr (EPI == EPI_GELU_BWD) {
             const h16* zs = (const h16*)p.R + (size_t)m * p.ldr + n0;
@@ -247,7 +259,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
     };
     auto apply_block = [&](int tile, auto cc) {
         constexpr int c = decltype(cc)::value;
-        const int bm = tile / tilesN, bn = tile - bm * tilesN;
+        int bn; const int bm = bm_of(tile, bn);
         const int m = bm * BM + c * 16 + fr, n0 = bn * BN + wn * 64 + fg * 16;
         f32x4 v[4];
 #pragma unroll
@@ -294,7 +306,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
     auto t_finalize = [&](int tile, int stage) {
         if constexpr (ND > 0) {
             h16* dA = sm + stage * STG + (wn * 32) * BK;
-            const int bm = tile / tilesN;
+            int bn_; const int bm = bm_of(tile, bn_);
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
                 const int row = ii * 16 + fr;
@@ -408,7 +420,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
     }
     // the group that computed the last slot still owes its epilogue
     if (pending >= 0) {
-        const int bm = pending / tilesN, bn = pending - bm * tilesN;
+        int bn; const int bm = bm_of(pending, bn);
         const int n0 = PERM ? bn * BN + wn * 64 + fg * 16 : bn * BN + wn * 64 + fg * 4;
         f32x4 b2[4];
 #pragma unroll

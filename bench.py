@@ -23,6 +23,7 @@ import argparse
 import ctypes
 import importlib
 import json
+import re
 import os
 import sys
 import time
@@ -197,6 +198,11 @@ def pmc_traffic(kernel):
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
         if t.get("_meta", {}).get("kernel_source_sha16") != kernel_source_sha16():
             return None
+        # the library's profiling scopes name the ping-pong GEMM "gemm_pp_kernel<EPI>" / "<EPI, down N>"; rocprofv3 reports the
+        # template arguments "<EPI, N>"
+        m = re.fullmatch(r"gemm_pp_kernel<(\d+)(?:, down (\d+))?>", kernel)
+        if m:
+            kernel = f"gemm_pp_kernel<{m.group(1)}, {m.group(2) or 0}>"
         return t[kernel]["hbm_bytes_per_launch"]
     except Exception:
         return None

@@ -345,7 +345,7 @@ def test_per_image_attention_kernels_with_fused_lora_down(image_size, batch, r, 
     logits2 = eng2.forward(xn.cuda(), normalise=False, train=train).cpu()
     eng2.loss_ce(y.cuda())
     gx2, _ = eng2.backward(True, False, tuple(x.shape))
-    assert rel_l2(logits, logits2) < 5e-4 and rel_l2(gx.cpu(), gx2.cpu()) < 1e-3
+    assert rel_l2(logits, logits2) < 1e-3 and rel_l2(gx.cpu(), gx2.cpu()) < 2e-3      # two fp16 kernels, each within TOL of the oracle
 
 
 @pytest.mark.parametrize("shape", [(128 * 50, 3072, 768, 64), (128 * 100, 768, 3072, 64), (128 * 110, 3072, 768, 0),

@@ -34,11 +34,11 @@ int main(int argc, char** argv) {
     hipEventRecord(e0); k_attention32_bwd(qkv, ctx, dctx, lse, dqkv, B, T, H, D, 0); hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
     printf("bwd per-head kernel %.1f us\n", ms * 1e3);
-    const char* names[] = {"A loop (0->1)", "A tail (1->2)", "A barrier wait (2->3)", "B loop (3->4)", "B tail (4->5)", "B barrier wait (5->6)", "head (0->6)"};
-    const int a[] = {0, 1, 2, 3, 4, 5, 0}, b2[] = {1, 2, 3, 4, 5, 6, 6};
+    const char* names[] = {"A loop (0->1)", "A tail (1->2)", "A barrier wait (2->3)", "B loop (3->4)", "B down+stores (4->7)", "B fetch_a (7->5)", "B barrier wait (5->6)", "head (0->6)"};
+    const int a[] = {0, 1, 2, 3, 4, 7, 5, 0}, b2[] = {1, 2, 3, 4, 7, 5, 6, 6};
     for (int wv = 0; wv < 8; ++wv) {
         printf("wave %d:", wv);
-        for (int k = 0; k < 7; ++k) {
+        for (int k = 0; k < 8; ++k) {
             double sum = 0; int n = 0;
             for (int blk = 0; blk < B; ++blk) {
                 const unsigned long long* s = &st[(blk * 8 + wv) * 8];
