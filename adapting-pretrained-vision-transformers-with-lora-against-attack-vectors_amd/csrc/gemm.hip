@@ -168,6 +168,7 @@ void set_attr() {
 
 int g_force_small = -1;
 int g_dephase = -1;
+int g_tile_group = -1;
 
 }  // namespace
 
@@ -193,6 +194,7 @@ int gemm_init(int device) {
     g_force_small = (e && e[0] == '1') ? 1 : 0;
     const char* dp = getenv("VITLORA_DEPHASE");      // experiment knob: start-offset unit of gemm256
     if (dp) g_dephase = atoi(dp);
+    if (const char* tg = getenv("VITLORA_TILE_GROUP")) g_tile_group = atoi(tg);     // experiment knob: gemm256 tile walk
     if (g_attr_err) return g_attr_err;
     done[device] = true;
     return 0;
@@ -213,6 +215,7 @@ void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
     if (bn != 64 && g_force_small != 1 && gemm256_supports(a, epi)) {
         GemmArgs b = a;
         if (g_dephase >= 0) b.dephase = g_dephase;
+        if (g_tile_group >= 0) b.tile_group = g_tile_group;
         launch_gemm256(b, epi, s);
         return;
     }

@@ -322,6 +322,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
         if (bid >= cnt) return -1;
         return base + xcd_remap(bid, cnt);
     };
+    // tile id -> (bm, bn): groups of GM tile rows walked column by column (bm fastest inside a group): the 32 consecutive ids
+    // of an XCD's workgroups then cover GM row panels x 32/GM W panels instead of 2-3 row panels x every W panel, and W
+    // (4.7 MB for N = 3072, more than one XCD's L2) is not re-streamed by every XCD in every round
+    // (wide outputs only: with 3 W panels the row-major walk already keeps them resident and grouping re-reads A; measured
+    //  L2-miss bytes per launch, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE: N = 3072 fc1 1060 -> 961 MB, fc2 dgrad 1081 -> 978 MB;
+    //  N = 768 / K = 3072 would go 428 -> 538 MB; launch times equal within noise either way)
+    const int GM = p.tile_group > 0 ? p.tile_group : (tilesN >= 8 ? 8 : 1);
+    const int tilesM = ntiles / tilesN;
+    auto bm_of = [&](int tile, int& bn) -> int {
+        const int per_group = GM * tilesN;
+        const int g = tile / per_group, r = tile - g * per_group;
+        const int rows = min(GM, tilesM - g * GM);
+        bn = r / rows;
+        return bm0 + g * GM + (r - bn * rows);
+    };
     int cur = tile_of(0);
     if (cur < 0) return;
     // De-phase the workgroups: without this every CU computes, then every CU stores its tile at
@@ -331,13 +346,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
         for (int i = (bid >> 3) & 3; i > 0; --i)
             for (int j = 0; j < p.dephase; ++j) __builtin_amdgcn_s_sleep(127);
     }
-    prologue(bm0 + cur / tilesN, cur % tilesN);
+    int cbn;
+    int cbm = bm_of(cur, cbn);
+    prologue(cbm, cbn);
     for (int it = 0; cur >= 0; ++it) {
         const int nxt = tile_of(it + 1);
-        run_tile(bm0 + cur / tilesN, cur % tilesN, it == 0, it, [&]() {
-            if (nxt >= 0) prologue(bm0 + nxt / tilesN, nxt % tilesN);
+        int nbn = 0;
+        const int nbm = nxt >= 0 ? bm_of(nxt, nbn) : 0;
+        run_tile(cbm, cbn, it == 0, it, [&]() {
+            if (nxt >= 0) prologue(nbm, nbn);
         });
-        cur = nxt;
+        cur = nxt; cbm = nbm; cbn = nbn;
     }
 }
 
