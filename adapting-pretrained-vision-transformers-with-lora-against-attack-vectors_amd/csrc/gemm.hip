@@ -207,9 +207,7 @@ void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
     const double flops = 2.0 * mv * (a.n_algo ? a.n_algo : a.N) * (a.K1 + (a.k2_algo ? a.k2_algo : a.K2));
     char name[64];
     if (bn != 64 && g_force_small != 1 && gemm_pp_supports(a, epi)) {
-        GemmArgs b = a;
-        if (g_dephase >= 0) b.dephase = g_dephase;
-        launch_gemm_pp(b, epi, s);
+        launch_gemm_pp(a, epi, s);
         return;
     }
     if (bn != 64 && g_force_small != 1 && gemm256_supports(a, epi)) {

@@ -127,7 +127,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
     const int nk1 = p.K1 / BK;
     const int nk = nk1 + p.K2 / BK;
     const int G = gridDim.x, bid = (int)blockIdx.x;
-    const bool dbg_nodma = p.dephase == 101, dbg_nowait = p.dephase == 102;   // timing experiments only (results invalid)
 
     const unsigned voA1 = ((unsigned)lr * (unsigned)p.lda1 + csw) * 2u, voA2 = ((unsigned)lr * (unsigned)p.lda2 + csw) * 2u;
     const unsigned voW1 = (wl * (unsigned)p.ldw1 + csw) * 2u, voW2 = (wl * (unsigned)p.ldw2 + csw) * 2u;
@@ -341,7 +340,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
     auto helper_static = [&](auto ss, int tile_prev, int t_cur, int stage) {
         constexpr int S = decltype(ss)::value;
         const bool have_prev = tile_prev >= 0;
-        if (!dbg_nodma) issue_ktile(IC<1>{}, t_cur, S + 2, (stage + 2) % NSTAGE);
+        issue_ktile(IC<1>{}, t_cur, S + 2, (stage + 2) % NSTAGE);
         if constexpr (S == 0) t_zero();
         t_accumulate(stage);
         if (have_prev) {
@@ -356,7 +355,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
         }
         // the DMA of the previous step has landed; what was issued after it may stay in flight
         constexpr int mine = post_ops(S - 1) + NDMA + post_ops(S);
-        if (!dbg_nowait) { if (have_prev) VMCNT(mine); else VMCNT(NDMA); }
+        if (have_prev) VMCNT(mine); else VMCNT(NDMA);
         BARRIER();
     };
 
@@ -399,7 +398,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
                 const int T = s + 2;
                 const int tgt = T < nk ? t_cur : t_next;
                 int issued = 0;
-                if (tgt >= 0 && !dbg_nodma) {
+                if (tgt >= 0) {
                     issue_ktile(IC<0>{}, tgt, T < nk ? T : T - nk, (st + 2) % NSTAGE);
                     issued = (ND > 0 && T < nk && T >= nk1) ? 8 : NDMA;
                 }
@@ -409,7 +408,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
                     t_finalize(t_cur, st == NSTAGE - 1 ? 0 : st + 1);
                     if (p.down_out) extra += 2 * ND;
                 }
-                if (!dbg_nowait) vmcnt_rt(issued ? issued + extra : 0);
+                vmcnt_rt(issued ? issued + extra : 0);
                 BARRIER();
                 adv();
             }
