@@ -45,6 +45,7 @@ namespace {
 
 constexpr int HD = 64;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x16 mfma32(h16x8 a, h16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -653,10 +654,15 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_fwd_img_kernel(const h16*
 #pragma unroll
                         for (int dt = 0; dt < 2; ++dt) vfr[st][dt] = tr_frag_o(sV, kt, st, fo.tr[dt]);
                     __builtin_amdgcn_sched_barrier(0);
-                    float ps = 0.f;
+                    f32x2 ps2 = {0.f, 0.f};                 // packed fp32 fma / add: two elements per VALU instruction
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { S[kt][r] = fexp2(fmaf(S[kt][r], scale_log2e, mc)); ps += S[kt][r]; }
-                    l += ps;
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 t = f32x2{S[kt][r], S[kt][r + 1]} * f32x2{scale_log2e, scale_log2e} + f32x2{mc, mc};
+                        const f32x2 p = {fexp2(t[0]), fexp2(t[1])};
+                        S[kt][r] = p[0]; S[kt][r + 1] = p[1];
+                        ps2 += p;
+                    }
+                    l += ps2[0] + ps2[1];
 #pragma unroll
                     for (int st = 0; st < 2; ++st) {
                         const h16x8 pb = pack8(S[kt], st);
@@ -820,11 +826,17 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_bwd_img_kernel(const h16*
                     s = mfma32(row_frag_o(sK, kt, fo.row[ks]), fa[ks], s);                     // S^T[key][q]
                     dp = mfma32(row_frag_o(sV, kt, fo.row[ks]), fb[ks], dp);                   // dP^T[key][q]
                 }
+                // two elements per VALU instruction where the ISA has a packed fp32 form (fma, sub, mul); exp2 stays scalar
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float p = fexp2(fmaf(s[r], scale_log2e, -lse_q));
-                    if constexpr (MASKED) { if (kt * 32 + (r & 3) + 8 * (r >> 2) >= tcut) p = 0.f; }
-                    dp[r] = p * (dp[r] - delta_q);
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 t = f32x2{s[r], s[r + 1]} * f32x2{scale_log2e, scale_log2e} - f32x2{lse_q, lse_q};
+                    f32x2 p = {fexp2(t[0]), fexp2(t[1])};
+                    if constexpr (MASKED) {
+                        if (kt * 32 + (r & 3) + 8 * (r >> 2) >= tcut) p[0] = 0.f;
+                        if (kt * 32 + ((r + 1) & 3) + 8 * ((r + 1) >> 2) >= tcut) p[1] = 0.f;
+                    }
+                    const f32x2 d = p * (f32x2{dp[r], dp[r + 1]} - f32x2{delta_q, delta_q});
+                    dp[r] = d[0]; dp[r + 1] = d[1];
                 }
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
