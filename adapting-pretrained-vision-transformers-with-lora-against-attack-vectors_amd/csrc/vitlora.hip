@@ -996,6 +996,11 @@ int vl_check_gemm(int M, int N, int K1, int K2, int epi, int pp_mode, float* max
     h16 *A = nullptr, *W = nullptr, *A2 = nullptr, *W2 = nullptr, *Wd = nullptr, *T2 = nullptr;
     float *R = nullptr, *bias = nullptr;
     char *C[2] = {nullptr, nullptr}, *C2[2] = {nullptr, nullptr};
+    struct Guard {                                   // frees the scratch operands and restores the ping-pong switch on every path
+        std::vector<void**> ptrs; int pp_keep;
+        ~Guard() { for (void** q : ptrs) if (*q) (void)hipFree(*q); gemm_pp_set_mode(pp_keep); }
+    } guard{{(void**)&A, (void**)&W, (void**)&A2, (void**)&W2, (void**)&Wd, (void**)&T2, (void**)&R, (void**)&bias,
+             (void**)&C[0], (void**)&C[1], (void**)&C2[0], (void**)&C2[1]}, gemm_pp_mode()};
     const size_t nA = (size_t)M * K1, nW = (size_t)N * K1, nC = (size_t)M * N;
     HIPCHK(hipMalloc(&A, nA * 2)); HIPCHK(hipMalloc(&W, nW * 2));
     HIPCHK(hipMalloc(&A2, (size_t)M * 64 * 2 + 256)); HIPCHK(hipMalloc(&W2, (size_t)N * 64 * 2 + 256));
@@ -1012,7 +1017,6 @@ int vl_check_gemm(int M, int N, int K1, int K2, int epi, int pp_mode, float* max
         d.C = A2; d.ldc = 64;
         launch_gemm(d, EPI_STORE_H16, 64, 0);
     }
-    const int keep = gemm_pp_mode();
     for (int i = 0; i < 2; ++i) {
         HIPCHK(hipMemset(C[i], 0, nC * 4)); HIPCHK(hipMemset(C2[i], 0, nC * 2));
         GemmArgs g = gemm_args(A, K1, W, K1, K1, M, N);
@@ -1022,13 +1026,12 @@ int vl_check_gemm(int M, int N, int K1, int K2, int epi, int pp_mode, float* max
         gemm_pp_set_mode(i == 0 ? 0 : (pp_mode ? 1 : 0));
         if (i == 1 && nd) {
             g.A2 = nullptr; g.down_W = Wd; g.down_ldw = K1; g.down_out = T2; g.down_ld = 64; g.down_groups = nd;
-            if (!gemm_pp_fuses_down(g, epi)) { gemm_pp_set_mode(keep); return fail(VL_ERR_UNSUPPORTED, "shape not fusable"); }
+            if (!gemm_pp_fuses_down(g, epi)) return fail(VL_ERR_UNSUPPORTED, "shape not fusable");
         }
         const int keep_small = gemm_force_small(i == 0 ? 1 : 0);
         launch_gemm(g, epi, 128, 0);
         gemm_force_small(keep_small);
     }
-    gemm_pp_set_mode(keep);
     HIPCHK(hipDeviceSynchronize());
     const bool f32out = epi == EPI_RESID_F32 || epi == EPI_STORE_F32;
     const size_t bytes = nC * (f32out ? 4 : 2);
@@ -1057,9 +1060,6 @@ int vl_check_gemm(int M, int N, int K1, int K2, int epi, int pp_mode, float* max
         cmp(t0.data(), t1.data(), false, (size_t)M * 64);
     }
     *max_diff = (float)md;
-    (void)hipFree(A); (void)hipFree(W); (void)hipFree(A2); (void)hipFree(W2); (void)hipFree(R); (void)hipFree(bias);
-    (void)hipFree(Wd); (void)hipFree(T2);
-    for (int i = 0; i < 2; ++i) { (void)hipFree(C[i]); (void)hipFree(C2[i]); }
     return VL_OK;
 }
 
