@@ -366,3 +366,27 @@ def test_main_gemm_kernels_agree_bitwise(shape):
             d = C.c_float(-1.0)
             assert lib.vl_check_gemm(M, N, K1, K2, epi, mode, C.byref(d)) == 0, lib.vl_last_error()
             assert d.value <= (4e-3 if epi == 2 else 0.0), (name, mode, d.value)
+
+
+def test_residual_add_in_the_gemm_epilogue_mode(monkeypatch):
+    """VITLORA_RESID=epilogue (read when the handle is created): o-proj and fc2 add the fp32 residual in their GEMM epilogue
+    (fp32 output in the natural MFMA column order) instead of handing a 16-bit delta to the next LayerNorm.  Same tolerances
+    as the default placement, and the two placements agree to fp16 rounding."""
+    cfg, w, lora, x, y = make_case(image_size=224, hidden=256, heads=4, mlp=1024, layers=2, batch=3, r=8)
+    _, g_ref, lg_ref = O.loss_and_input_grad(w, cfg, x, y, lora)
+    outs = []
+    for mode in ("epilogue", None):
+        if mode:
+            monkeypatch.setenv("VITLORA_RESID", mode)
+        else:
+            monkeypatch.delenv("VITLORA_RESID", raising=False)
+        eng = make_engine(cfg, w, lora, precision="f16")
+        logits = eng.forward(x.cuda(), normalise=True).cpu()
+        eng.loss_ce(y.cuda())
+        gx, _ = eng.backward(True, False, tuple(x.shape))
+        torch.cuda.synchronize()
+        assert rel_l2(logits, lg_ref) < TOL_ACT["f16"], mode
+        assert rel_l2(gx.cpu(), g_ref) < TOL_GRAD["f16"], mode
+        outs.append((logits, gx.cpu()))
+    assert rel_l2(outs[0][0], outs[1][0]) < 2e-3 and rel_l2(outs[0][1], outs[1][1]) < 3e-3
+    assert not torch.equal(outs[0][0], outs[1][0])       # the switch really selected another path
