@@ -96,3 +96,33 @@ def test_train_loras_synthetic_with_pgd_inner_loop(tmp_path):
     r = res["google_vit"]["mapillary"]["pgd"][4]
     assert len(r["train_loss"]) == 2 and all(np.isfinite(v) for v in r["train_loss"] + r["val_loss"])
     assert os.path.isdir(os.path.join(str(tmp_path), "google_vit", "mapillary", "pgd", "rank4_best_adapter"))
+
+
+def test_two_rank_attack_generation_equals_single_process(tmp_path):
+    """whitebox_attacks.py under `torch.distributed.run` with two ranks (both on cuda:0: VITLORA_SHARE_GPU=1, the only GPU of
+    the box; coordination over gloo as in production): interleaved shards, no data-path collective, barrier + file-name
+    exchange before rank 0 reports.  Every PNG must be byte-identical to the single-process run's: FGSM of an image does not
+    depend on which rank or batch it was in, as long as the batches have the same SIZE (the mean loss puts 1/B into the
+    gradient before the sign; 32 images in batches of 8 on both sides -- a ragged split would round 1/5 and 1/3 differently
+    and may flip the sign of a near-zero gradient entry, in the reference just the same)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--models", "google_vit", "--sources", "mapillary", "--synthetic", "32", "--arch", "tiny", "--attacks", "fgsm",
+              "--splits", "test", "--batch_size", "8", "--num_classes", "5"]
+    env = dict(os.environ, VITLORA_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    r1 = subprocess.run([sys.executable, os.path.join(root, "whitebox_attacks.py"), "--output_dir", one] + common, env=env,
+                        capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", "29533", os.path.join(root, "whitebox_attacks.py"), "--output_dir", two] + common,
+                        env=env, capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    d1 = os.path.join(one, "google_vit", "mapillary", "test", "fgsm", "images")
+    d2 = os.path.join(two, "google_vit", "mapillary", "test", "fgsm", "images")
+    names = sorted(os.listdir(d1))
+    assert len(names) == 32 and sorted(os.listdir(d2)) == names
+    for n in names:
+        assert open(os.path.join(d1, n), "rb").read() == open(os.path.join(d2, n), "rb").read(), n
+    assert "32 images per attack" in r2.stdout

@@ -18,6 +18,7 @@ x + delta/std.  Extensions, all opt-in:
 import argparse
 import importlib
 import os
+import zlib
 import sys
 
 import torch
@@ -86,7 +87,8 @@ def batches(args, split, class_to_idx, model, rank, world):
     if args.synthetic:
         syn = importlib.import_module(V.__name__ + ".synthetic")
         arch = importlib.import_module(V.__name__ + ".attacks")._unwrap(model).arch
-        x, y = syn.random_batch(arch, args.synthetic, seed=args.seed + hash(split) % 1000)
+        # zlib.crc32, not hash(): str hashes are salted per process, and every rank must draw the SAME synthetic split
+        x, y = syn.random_batch(arch, args.synthetic, seed=args.seed + zlib.crc32(split.encode()) % 1000)
         names = [f"{split}_{i:06d}.png" for i in range(args.synthetic)]
         idx = list(range(rank, args.synthetic, world))
         for s in range(0, len(idx), args.batch_size):
@@ -109,7 +111,8 @@ def main(argv=None):
     if not args.synthetic and not args.data_root:
         raise SystemExit("--data_root is required unless --synthetic N is given")
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    # one process per GPU; VITLORA_SHARE_GPU=1 (rehearsal on a one-GPU box, tests/test_hip_pipeline.py) puts every rank on cuda:0
+    device = torch.device("cuda", 0 if os.environ.get("VITLORA_SHARE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", 0)))
     print(f"Using device: {device} (rank {rank}/{world})")
     dist = None
     if world > 1:
