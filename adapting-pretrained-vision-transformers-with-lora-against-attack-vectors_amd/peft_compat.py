@@ -221,12 +221,13 @@ def get_peft_model(model: ViTForImageClassification, peft_config: LoraConfig, se
     return PeftModel._attach(model, peft_config, init_B_zero=True, seed=seed)
 
 
-def setup_peft_lora(model, rank=16, alpha=16, dropout=0.1, target_modules=None):
-    """train_loras.py:79-95, same defaults."""
+def setup_peft_lora(model, rank=16, alpha=16, dropout=0.1, target_modules=None, seed=None):
+    """train_loras.py:79-95, same defaults.  `seed` (not in the reference) makes the kaiming-uniform A reproducible without
+    touching the global RNG; None = torch's global generator, as peft does."""
     if target_modules is None:
         target_modules = ["query", "key", "value", "output.dense"]
     cfg = LoraConfig(task_type=TaskType.SEQ_CLS, inference_mode=False, r=rank, lora_alpha=alpha, lora_dropout=dropout,
                      target_modules=target_modules)
-    pm = get_peft_model(model, cfg)
+    pm = get_peft_model(model, cfg, seed=seed)
     pm.print_trainable_parameters()
     return pm

@@ -126,3 +126,40 @@ def test_two_rank_attack_generation_equals_single_process(tmp_path):
     for n in names:
         assert open(os.path.join(d1, n), "rb").read() == open(os.path.join(d2, n), "rb").read(), n
     assert "32 images per attack" in r2.stdout
+
+
+def test_two_rank_lora_training_equals_single_process(tmp_path):
+    """train_loras.py --synthetic under `torch.distributed.run` with two ranks (one GPU shared, gloo instead of RCCL: the
+    collectives are the same calls) against one process: same number of optimizer steps on both ranks although 40 samples in
+    global batches of 16 leave a ragged last batch, ONE weighted all-reduce per step, initial adapters broadcast from rank 0.
+    The gradient of a global batch is the size-weighted mean of the shard gradients, so the trained adapters agree up to
+    summation order (fp32 mode, dropout 0: the LoRA dropout mask is indexed inside the LOCAL batch)."""
+    import subprocess
+    import sys
+    from safetensors.torch import load_file
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--synthetic", "40", "--arch", "tiny", "--attacks", "fgsm", "--ranks", "4", "--epochs", "2", "--batch_size", "16",
+              "--lora_dropout", "0", "--precision", "f32", "--num_classes", "5", "--lr", "1e-3"]
+    env = dict(os.environ, VITLORA_SHARE_GPU="1", VITLORA_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    outs = []
+    for tag, launcher in (("one", [sys.executable]),
+                          ("two", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                   "--master-addr", "127.0.0.1", "--master-port", "29534"])):
+        out = str(tmp_path / tag)
+        r = subprocess.run(launcher + [os.path.join(root, "train_loras.py"), "--output_dir", out] + common, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (tag, r.stdout[-1500:], r.stderr[-1500:])
+        d = os.path.join(out, "google_vit", "mapillary", "fgsm")
+        res = json.load(open(os.path.join(d, "results.json")))
+        outs.append((load_file(os.path.join(d, "rank4_final_adapter", "adapter_model.safetensors")), res))
+    (a1, r1), (a2, r2) = outs
+    assert a1.keys() == a2.keys() and len(a1) > 0
+    moved = 0.0
+    for k in a1:
+        x, y = a1[k].double(), a2[k].double()
+        assert (x - y).norm() <= 1e-3 * max(x.norm().item(), 1e-3), k
+        moved += x.norm().item()
+    assert moved > 0.0
+    k4 = next(iter(r1))                                    # results.json is keyed by the rank
+    for key, tol in (("train_loss", 1e-4), ("val_loss", 1e-4), ("train_acc", 1e-6), ("val_acc", 1e-6)):       # one entry per epoch
+        assert len(r1[k4][key]) == 2 and np.allclose(r1[k4][key], r2[k4][key], atol=tol), (key, r1[k4][key], r2[k4][key])

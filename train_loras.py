@@ -71,13 +71,21 @@ class Dist:
         self.world = int(os.environ.get("WORLD_SIZE", 1))
         self.rank = int(os.environ.get("RANK", 0))
         self.local = int(os.environ.get("LOCAL_RANK", 0))
+        # rehearsal on a one-GPU box (tests/test_hip_pipeline.py): VITLORA_SHARE_GPU=1 puts every rank on cuda:0 and
+        # VITLORA_DIST_BACKEND=gloo replaces RCCL, which refuses two ranks on one device
+        if os.environ.get("VITLORA_SHARE_GPU") == "1":
+            self.local = 0
         self.device = torch.device("cuda", self.local)
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             torch.cuda.set_device(self.local)
             if not dist.is_initialized():
-                dist.init_process_group("nccl", device_id=self.device)
+                backend = os.environ.get("VITLORA_DIST_BACKEND", "nccl")
+                if backend == "nccl":
+                    dist.init_process_group("nccl", device_id=self.device)
+                else:
+                    dist.init_process_group(backend)
 
     def sum_(self, t):
         if self.world > 1:
@@ -159,7 +167,7 @@ def evaluate(peft_model, dset, args, D, mean, std, criterion=None):
 
 def train_rank(args, D, base_model, sets, rank_r, out_dir, mean, std):
     """One adapter: train_loras.py:269-385."""
-    peft_model = V.setup_peft_lora(base_model, rank=rank_r, dropout=args.lora_dropout)
+    peft_model = V.setup_peft_lora(base_model, rank=rank_r, dropout=args.lora_dropout, seed=args.seed + 31 * rank_r)   # reproducible init
     vit = peft_model._vit
     engine = vit._engine()
     if D.world > 1:
