@@ -58,7 +58,17 @@ class AdversarialPatchPyTorch:
         self.patch_type, self.optimizer, self.targeted, self.verbose = patch_type, optimizer, bool(targeted), verbose
         self.mean, self.std = list(mean or IMAGENET_MEAN), list(std or IMAGENET_STD)
         self.group = process_group
-        self._gen = torch.Generator().manual_seed(int(seed))
+        # two streams: the transformations drawn per image (rank-specific under a process group: every rank draws for its own
+        # shard) and the batch order (the SAME on every rank, or the shards of a global batch would not belong together)
+        rank = 0
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                rank = dist.get_rank(process_group)
+        except Exception:
+            rank = 0
+        self._gen = torch.Generator().manual_seed(int(seed) + 1000003 * rank)
+        self._gen_order = torch.Generator().manual_seed(int(seed) + 7)
         ps = patch_shape[1]
         # ART: the patch starts at the middle of the classifier's clip_values = (0, 1)
         self._patch = torch.full((3, ps, ps), 0.5, dtype=torch.float32, device=self.eng.device)
@@ -91,25 +101,36 @@ class AdversarialPatchPyTorch:
         return torch.tensor(m, dtype=torch.float32, device=self.eng.device)
 
     # -- one optimiser step -----------------------------------------------------------------------------------
-    def train_step(self, images: torch.Tensor, labels: torch.Tensor, params=None) -> torch.Tensor:
-        """ART `_train_step`: returns the CE of the patched batch before the update."""
+    def train_step(self, images: torch.Tensor, labels: torch.Tensor, params=None, global_count: int = 0) -> torch.Tensor:
+        """ART `_train_step`: returns the CE of the patched batch before the update.  Under a process group `images` is this
+        rank's shard of a global batch of `global_count` images (possibly empty): the patch gradient of the global mean loss
+        is the shard-size-weighted sum of the ranks' gradients, ONE all-reduce of [3, ps, ps] floats."""
         eng = self.eng
-        images = images.to(device=eng.device, dtype=torch.float32).contiguous()
-        labels = labels.to(device=eng.device, dtype=torch.int64).contiguous()
-        params = params if params is not None else self.sample_params(images.shape[0])
-        self.last_params = params
-        mats = self._matrices(params)
         ptype = 1 if self.patch_type == "circle" else 0
-        eng.set_normalization(self.mean, self.std)
-        patched = eng.patch_apply(images, self._patch, mats, ptype)
-        eng.forward(patched, normalise=True, train=False)
-        ce = eng.loss_ce(labels)
-        gx, _ = eng.backward(True, False, tuple(images.shape))
-        g = eng.patch_grad(gx, mats, self.patch_shape[1], ptype)          # d CE / d patch
+        n_local = int(images.shape[0])
+        if n_local:
+            images = images.to(device=eng.device, dtype=torch.float32).contiguous()
+            labels = labels.to(device=eng.device, dtype=torch.int64).contiguous()
+            params = params if params is not None else self.sample_params(n_local)
+            self.last_params = params
+            mats = self._matrices(params)
+            eng.set_normalization(self.mean, self.std)
+            patched = eng.patch_apply(images, self._patch, mats, ptype)
+            eng.forward(patched, normalise=True, train=False)
+            ce = eng.loss_ce(labels)
+            gx, _ = eng.backward(True, False, tuple(images.shape))
+            g = eng.patch_grad(gx, mats, self.patch_shape[1], ptype)          # d CE / d patch (mean over the local images)
+        else:
+            ce = torch.zeros((), device=eng.device)
+            g = torch.zeros_like(self._patch)
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(g, group=self.group)                          # 12 KB at ps = 32
-            g /= dist.get_world_size(self.group)
+            if global_count:
+                g.mul_(n_local / float(global_count))
+                dist.all_reduce(g, group=self.group)                      # 12 KB at ps = 32
+            else:                                                         # equal shards assumed
+                dist.all_reduce(g, group=self.group)
+                g /= dist.get_world_size(self.group)
         # ART minimises loss = -CE (untargeted, Adam) or +CE (targeted); "pgd": patch += / -= lr * sign(grad)
         ascent = not self.targeted
         if self.optimizer == "pgd":
@@ -127,11 +148,18 @@ class AdversarialPatchPyTorch:
         y = torch.as_tensor(y)
         if y.dim() == 2:
             y = y.argmax(1)
+        import torch.distributed as dist
+        world, rank = 1, 0
+        if dist.is_available() and dist.is_initialized():
+            world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
         for it in range(self.max_iter):
-            order = torch.randperm(x.shape[0], generator=self._gen)           # ART's DataLoader(shuffle=True)
+            order = torch.randperm(x.shape[0], generator=self._gen_order)     # ART's DataLoader(shuffle=True); same on every rank
             for s0 in range(0, x.shape[0], self.batch_size):
                 idx = order[s0:s0 + self.batch_size]
-                ce = self.train_step(x[idx], y[idx])
+                if world > 1:                                                 # this rank's images of the global batch
+                    ce = self.train_step(x[idx[rank::world]], y[idx[rank::world]], global_count=len(idx))
+                else:
+                    ce = self.train_step(x[idx], y[idx])
             if self.verbose and (it % 50 == 0 or it == self.max_iter - 1):
                 print(f"  patch iter {it + 1}/{self.max_iter}: CE {float(ce):.4f}")
         mask = self.patch_mask()

@@ -9,8 +9,8 @@ patch, clip to [0, 1]), then paste it on every image of the split at a random sc
 
 The EoT loop runs on the HIP engine (patch.py: vl_patch_apply -> vl_forward -> vl_loss_ce -> vl_backward_input ->
 vl_patch_grad -> vl_adam_step -> vl_clamp).  Extensions: --synthetic N, --arch tiny|vit_b|vit_l, --lora_dir DIR,
---precision; under torch.distributed.run every rank optimises on its shard of each batch and the [3, ps, ps] patch
-gradient is all-reduced (RCCL).
+--precision; under torch.distributed.run every rank optimises on its shard of each global batch, the [3, ps, ps] patch
+gradient is all-reduced weighted by shard size (RCCL), and the split's batches are patched round-robin by the ranks.
 """
 import argparse
 import importlib
@@ -65,7 +65,21 @@ def build_parser():
 def main(argv=None):
     args = build_parser().parse_args(argv)
     location = (args.patch_location_x, args.patch_location_y) if args.patch_location_x is not None and args.patch_location_y is not None else None
-    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    # one process per GPU; VITLORA_SHARE_GPU=1 / VITLORA_DIST_BACKEND=gloo: rehearsal on a one-GPU box
+    local = 0 if os.environ.get("VITLORA_SHARE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", 0))
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        if not dist.is_initialized():
+            backend = os.environ.get("VITLORA_DIST_BACKEND", "nccl")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=device)
+            else:
+                dist.init_process_group(backend)
     random.seed(args.seed)
     mean, std = V.get_normalization(args.model)
     if args.synthetic:
@@ -100,11 +114,13 @@ def main(argv=None):
                 x_all, y_all = syn.random_batch(arch, args.synthetic, seed=args.seed + sum(map(ord, split)))
                 names = [f"{split}_{i:06d}.png" for i in range(args.synthetic)]
                 fetch = lambda idx: (x_all[idx], y_all[idx], [names[i] for i in idx])
+                name_of = lambda i: names[i]
                 n = args.synthetic
             else:
                 meta = os.path.join(args.data_root, split, "metadata.csv")
                 ds = iomod.FolderDataset(args.data_root, meta, class_to_idx, image_size=arch.image_size, sources=[args.source])
                 n = len(ds)
+                name_of = lambda i: ds.filenames[i]
 
                 def fetch(idx):
                     items = [ds[i] for i in idx]
@@ -118,20 +134,28 @@ def main(argv=None):
                 batch_size=args.batch_size, patch_shape=(3, args.patch_size, args.patch_size), patch_location=location,
                 patch_type=patch_type, optimizer=args.optimizer, targeted=args.targeted, verbose=args.verbose, seed=args.seed,
                 mean=mean, std=std)
-            patch, _ = attack.generate(x=x_train, y=y_train)
-            np.save(os.path.join(base_out, "patch.npy"), patch)
+            patch, _ = attack.generate(x=x_train, y=y_train)               # every rank ends with the same patch (all-reduced steps)
+            if rank == 0:
+                np.save(os.path.join(base_out, "patch.npy"), patch)
             all_filenames = []
-            for s0 in range(0, n, args.batch_size):
-                images, _, filenames = fetch(list(range(s0, min(n, s0 + args.batch_size))))
-                scale = random.uniform(args.scale_min_apply, args.scale_max_apply)          # one scale per batch (:201)
+            for bi, s0 in enumerate(range(0, n, args.batch_size)):
+                idx = list(range(s0, min(n, s0 + args.batch_size)))
+                scale = random.uniform(args.scale_min_apply, args.scale_max_apply)          # one scale per batch (:201); drawn by every rank
+                if bi % world != rank:                                                      # batches are dealt round-robin to the ranks
+                    all_filenames.extend(name_of(i) for i in idx)
+                    continue
+                images, _, filenames = fetch(idx)
                 patched = attack.apply_patch(images.to(device), scale=scale)
                 all_filenames.extend(filenames)
                 iomod.save_images(patched, filenames, out_dir, engine=engine)
-            if not args.synthetic:
+            if dist is not None:
+                dist.barrier()                                                              # every PNG is on disk before the metadata
+            if not args.synthetic and rank == 0:
                 meta_out = iomod.create_adv_metadata(os.path.join(args.data_root, split, "metadata.csv"), all_filenames, out_dir)
                 meta_out["image_path"] = meta_out["image_path"].apply(lambda p: os.path.abspath(p) if not os.path.isabs(p) else p)
                 meta_out.to_csv(os.path.join(base_out, "metadata.csv"), index=False)
-            print(f"{patch_type.capitalize()} patch attack results saved to: {base_out}")
+            if rank == 0:
+                print(f"{patch_type.capitalize()} patch attack results saved to: {base_out}")
 
 
 if __name__ == "__main__":

@@ -163,3 +163,33 @@ def test_two_rank_lora_training_equals_single_process(tmp_path):
     k4 = next(iter(r1))                                    # results.json is keyed by the rank
     for key, tol in (("train_loss", 1e-4), ("val_loss", 1e-4), ("train_acc", 1e-6), ("val_acc", 1e-6)):       # one entry per epoch
         assert len(r1[k4][key]) == 2 and np.allclose(r1[k4][key], r2[k4][key], atol=tol), (key, r1[k4][key], r2[k4][key])
+
+
+def test_two_rank_patch_attack_cli(tmp_path):
+    """patch_attack.py --synthetic under `torch.distributed.run` with two ranks (one shared GPU, gloo): shards of every global
+    batch, ONE shard-size-weighted all-reduce of the patch gradient per step, batches of the split patched round-robin, rank 0
+    writes patch.npy.  With the deterministic "pgd" patch optimiser at a FIXED location / scale / zero rotation the
+    transformations do not depend on the rank's random stream, so the two-rank patch equals the single-process patch up to
+    the sign of near-zero gradient entries; every image of the split is written exactly once."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--model", "google_vit", "--source", "mapillary", "--synthetic", "24", "--arch", "tiny", "--num_classes", "5", "--patch_type", "square", "--splits", "test", "--batch_size", "8",
+              "--patch_sample_size", "24", "--patch_size", "16", "--max_iter", "3", "--optimizer", "pgd", "--learning_rate", "0.05",
+              "--rotation_max", "0", "--scale_min", "0.3", "--scale_max", "0.3", "--patch_location_x", "8", "--patch_location_y", "8",
+              "--precision", "f32"]
+    env = dict(os.environ, VITLORA_SHARE_GPU="1", VITLORA_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    patches = []
+    for tag, launcher in (("one", [sys.executable]),
+                          ("two", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                   "--master-addr", "127.0.0.1", "--master-port", "29536"])):
+        out = str(tmp_path / tag)
+        r = subprocess.run(launcher + [os.path.join(root, "patch_attack.py"), "--output_dir", out] + common, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (tag, r.stdout[-1500:], r.stderr[-1500:])
+        base = os.path.join(out, "google_vit", "mapillary", "test", "patch_square")
+        assert sorted(os.listdir(os.path.join(base, "images"))) == [f"test_{i:06d}.png" for i in range(24)]
+        patches.append(np.load(os.path.join(base, "patch.npy")))
+    p1, p2 = patches
+    assert p1.shape == p2.shape == (3, 16, 16) and np.abs(p1 - 0.5).max() > 0.04          # three sign steps of 0.05 moved it
+    assert (np.abs(p1 - p2) < 1e-6).mean() > 0.97
