@@ -18,6 +18,13 @@ from helpers import PKG, pkg
 
 pytestmark = pytest.mark.gpu
 
+
+def free_port() -> str:
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return str(so.getsockname()[1])
+
 CLASSES = ["stop", "yield", "speed_limit", "no_entry"]
 
 
@@ -116,7 +123,7 @@ def test_two_rank_attack_generation_equals_single_process(tmp_path):
                         capture_output=True, text=True, timeout=300)
     assert r1.returncode == 0, r1.stderr[-2000:]
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                         "127.0.0.1", "--master-port", "29533", os.path.join(root, "whitebox_attacks.py"), "--output_dir", two] + common,
+                         "127.0.0.1", "--master-port", free_port(), os.path.join(root, "whitebox_attacks.py"), "--output_dir", two] + common,
                         env=env, capture_output=True, text=True, timeout=300)
     assert r2.returncode == 0, r2.stderr[-2000:]
     d1 = os.path.join(one, "google_vit", "mapillary", "test", "fgsm", "images")
@@ -144,7 +151,7 @@ def test_two_rank_lora_training_equals_single_process(tmp_path):
     outs = []
     for tag, launcher in (("one", [sys.executable]),
                           ("two", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                                   "--master-addr", "127.0.0.1", "--master-port", "29534"])):
+                                   "--master-addr", "127.0.0.1", "--master-port", free_port()])):
         out = str(tmp_path / tag)
         r = subprocess.run(launcher + [os.path.join(root, "train_loras.py"), "--output_dir", out] + common, env=env,
                            capture_output=True, text=True, timeout=600)
@@ -182,7 +189,7 @@ def test_two_rank_patch_attack_cli(tmp_path):
     patches = []
     for tag, launcher in (("one", [sys.executable]),
                           ("two", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                                   "--master-addr", "127.0.0.1", "--master-port", "29536"])):
+                                   "--master-addr", "127.0.0.1", "--master-port", free_port()])):
         out = str(tmp_path / tag)
         r = subprocess.run(launcher + [os.path.join(root, "patch_attack.py"), "--output_dir", out] + common, env=env,
                            capture_output=True, text=True, timeout=600)
