@@ -200,3 +200,33 @@ def test_two_rank_patch_attack_cli(tmp_path):
     p1, p2 = patches
     assert p1.shape == p2.shape == (3, 16, 16) and np.abs(p1 - 0.5).max() > 0.04          # three sign steps of 0.05 moved it
     assert (np.abs(p1 - p2) < 1e-6).mean() > 0.97
+
+
+def test_bench_contract_one_and_two_ranks():
+    """bench.py prints ONE JSON line with the driver's keys; under `torch.distributed.run` (two ranks sharing the GPU, gloo:
+    BENCH_BACKEND / BENCH_SHARE_GPU) rank 0 alone prints it, n_gpus = 2 and the images of both ranks are counted."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    small = ["--steps", "1", "--warmup", "1", "--batch", "32", "--pgd-steps", "2", "--no-cpu-baseline", "--no-extras"]
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    lines = {}
+    for n, launcher in ((1, [sys.executable]),
+                        (2, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                             "127.0.0.1", "--master-port", free_port()])):
+        r = subprocess.run(launcher + [os.path.join(root, "bench.py"), "--gpus", str(n)] + small, env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, (n, r.stderr[-1500:])
+        js = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(js) == 1, r.stdout[-500:]
+        lines[n] = json.loads(js[0])
+    for n, d in lines.items():
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                    "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert key in d, (n, key)
+        assert d["n_gpus"] == n and d["steps"] == 1 and d["warmup"] == 1 and d["unit"] == "img/s" and d["scaling"] == "weak"
+        assert d["dtype"] == "f16" and d["data"] == "synthetic" and d["vs_baseline"] is None and d["higher_is_better"] is True
+        assert "workload" in d["config"] and d["config"]["global_batch"] == 32 * n
+        assert abs(d["value"] - 32 * n / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"]
+        rf = d["roofline"]
+        assert rf["bound"] in ("mfma", "hbm") and 0.0 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
