@@ -126,7 +126,7 @@ def wrap_lora(m, lora):
     return wrapped
 
 
-PGD_CASES = {"tiny17": (1, 3, 7), "vitb": (1, 3, 7)}
+PGD_CASES = {"tiny17": (1, 3, 7, 20), "vitb": (1, 3, 7, 20)}      # 20 = the headline attack length (BASELINE config 2)
 LORA_CASES = {"tiny17": (4, 8, 16), "tiny197": (8,), "vitb": (4, 8, 16)}
 LORA_TARGETS = ("q", "k", "v", "o", "fc2")          # ["query","key","value","output.dense"], train_loras.py:81
 

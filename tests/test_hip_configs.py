@@ -58,8 +58,10 @@ def test_golden_pgd_trajectories(name, prec):
         ref = x + torch.from_numpy(z[f"delta_x0_{k}"])
         same = ((adv - ref).abs() < 1e-6).float().mean().item()
         # every iteration re-decides sign(g) for all pixels: a flipped near-zero gradient entry moves that pixel by
-        # 2 alpha and later iterations see the difference, so agreement decays slowly with k
-        floor = {"f16": {1: 0.998, 3: 0.99, 7: 0.97}, "f32": {1: 0.9999, 3: 0.9995, 7: 0.999}}[prec][k]
+        # 2 alpha and later iterations see the difference, so agreement decays slowly with k (measured on ViT-B at k = 20, the
+        # headline attack length: 98.95 % in fp16 mode, 99.69 % in fp32 mode; the fp32 oracle itself: 99.84 %)
+        floor = {"f16": {1: 0.998, 3: 0.995, 7: 0.99, 20: 0.98}, "f32": {1: 0.9999, 3: 0.9995, 7: 0.999, 20: 0.994}}[prec][k]
+        print(f"G4 {name} {prec} k={k}: {same:.5f} of the pixels identical")
         assert same > floor, (name, k, same)
         assert (adv - x).abs().max().item() <= eps + 1e-6
 
