@@ -401,6 +401,15 @@ __global__ __launch_bounds__(256) void pgd_step_kernel(float* __restrict__ adv, 
     }
 }
 
+// Zero fill (bytes a multiple of 16, 16-byte aligned).  Used INSIDE captured sequences instead of hipMemsetAsync: a memset
+// node captured before the runtime's own fill kernel had ever run did not take effect on graph replays (ROCm 7.2;
+// tools/cold_capture_diag.py), a kernel node of the library's own code object does.
+__global__ __launch_bounds__(256) void zero_kernel(f32x4* __restrict__ p, int64_t n16) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = z;
+}
+
 // K11: counter-based uniform noise (splitmix64 finaliser on (seed, index)); not torch's stream
 // (random_start=True, whitebox_attacks.py:113, needs a seeded deterministic start, not that stream).
 // (mix64 lives in common.h: the LoRA dropout mask uses the same generator)
@@ -647,6 +656,11 @@ void k_pgd_step(float* adv, const float* x0, const float* grad, float eps, float
     const int64_t n4 = n / 4;
     hipLaunchKernelGGL(pgd_step_kernel, dim3(nblk(n4 > 0 ? n4 : 1, 256, 2048)), dim3(256), 0, s, adv, x0, grad, eps,
                        alpha, lo, hi, n4, n);
+}
+void k_zero(void* p, size_t bytes, hipStream_t s) {
+    ProfScope prof_("zero_kernel", 0.0, (double)bytes, s);
+    const int64_t n16 = (int64_t)(bytes / 16);
+    if (n16 > 0) hipLaunchKernelGGL(zero_kernel, dim3(nblk(n16, 256, 4096)), dim3(256), 0, s, (f32x4*)p, n16);
 }
 void k_pgd_init(float* adv, const float* x0, float eps, float lo, float hi, uint64_t seed, int64_t n, hipStream_t s) {
     ProfScope prof_("pgd_init_kernel", 0.0, (double)n * 8.0, s);

@@ -52,6 +52,8 @@ struct GemmArgs {
 void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s);
 int gemm_init(int device);
 int gemm_force_small(int v);   // 1: every GEMM on the 128-row kernel (self-check reference); returns the previous setting
+void gemm256_set_cus(int n);   // persistent grid size of the 256-row kernel (default: the device's CU count)
+void gemm_pp_set_cus(int n);
 int gemm_pp_mode();           // gemm_pp.hip: 0 = off, 1 = every supported shape, 2 = epilogue-heavy shapes only
 void gemm_pp_set_mode(int m);
 bool gemm_pp_fuses_down(const GemmArgs& a, int epi);   // a.down_* set: can launch_gemm run this GEMM with the down projection inside?   // per-device kernel attributes (outside any stream capture); 0 = ok

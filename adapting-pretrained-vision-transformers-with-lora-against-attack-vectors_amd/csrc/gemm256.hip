@@ -423,6 +423,8 @@ bool gemm256_supports(const GemmArgs& a, int epi) {
     return plan_tiles(a.M, a.N, g_num_cus ? g_num_cus : 256, &nb, &ns);
 }
 
+void gemm256_set_cus(int n) { g_num_cus = n; }
+
 int gemm256_init() {
     g_attr_err256 = 0;
     if (const char* tc = getenv("VITLORA_TAIL_COST")) g_tail_cost = atof(tc);

@@ -473,6 +473,7 @@ bool shape_ok(const GemmArgs& a) {
 
 }  // namespace
 
+void gemm_pp_set_cus(int n) { g_pp_cus = n; }
 int gemm_pp_mode() { return g_pp_mode; }
 void gemm_pp_set_mode(int m) { g_pp_mode = m; }
 

@@ -30,6 +30,7 @@ void k_head_bwd(const float* dlogits, const float* gscale, const float* Wc, cons
 void k_classifier_grad(const float* dlogits, const float* xf, int B, int D, int C, float* dW, float* db, hipStream_t s);
 void k_pgd_step(float* adv, const float* x0, const float* grad, float eps, float alpha, float lo, float hi, int64_t n,
                 hipStream_t s);
+void k_zero(void* p, size_t bytes, hipStream_t s);   // bytes % 16 == 0; a kernel node, not a memset node, under capture
 void k_pgd_init(float* adv, const float* x0, float eps, float lo, float hi, uint64_t seed, int64_t n, hipStream_t s);
 void k_adam(float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps, int t, int64_t n,
             hipStream_t s);

@@ -677,8 +677,8 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
         k_classifier_grad(w.dlogits, w.xf, B, D, m->C, flat_grad + m->cls_w_off, flat_grad + m->cls_b_off, s);
     }
     int cur = 0;
-    HIPCHK(hipMemsetAsync(w.dres[0], 0, (size_t)Mpad * D * sizeof(float), s));
-    HIPCHK(hipMemsetAsync(w.dres_h, 0, (size_t)Mpad * D * sizeof(h16), s));
+    k_zero(w.dres[0], (size_t)Mpad * D * sizeof(float), s);       // kernel nodes, not memset nodes: section 3.3 of DESIGN.md
+    k_zero(w.dres_h, (size_t)Mpad * D * sizeof(h16), s);
     k_head_bwd(w.dlogits, w.gscale, m->flat + m->cls_w_off, m->lnf_g, w.xhat, w.rstd_f, B, T, D, m->C, w.dres[0], w.dres_h, s);
 
     // LoRA weight gradients of one projection: dy [M,out], x [M,in], t/u [M,kext]
@@ -826,6 +826,52 @@ int vl_pgd_init(float* adv, const float* x0, float eps, float lo, float hi, uint
     return VL_OK;
 }
 
+// VITLORA_GRAPH_DUMP=<file>: append the node list of a captured iteration (type, kernel name, grid, block, dynamic LDS)
+static void dump_graph(hipGraph_t graph) {
+    const char* path = getenv("VITLORA_GRAPH_DUMP");
+    if (!path || !path[0]) return;
+    FILE* f = fopen(path, "a");
+    if (!f) return;
+    size_t n = 0;
+    if (hipGraphGetNodes(graph, nullptr, &n) != hipSuccess) { fclose(f); return; }
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n && hipGraphGetNodes(graph, nodes.data(), &n) != hipSuccess) { fclose(f); return; }
+    fprintf(f, "graph %zu nodes\n", n);
+    for (size_t i = 0; i < n; ++i) {
+        hipGraphNodeType ty;
+        if (hipGraphNodeGetType(nodes[i], &ty) != hipSuccess) { fprintf(f, "%zu ?\n", i); continue; }
+        if (ty == hipGraphNodeTypeKernel) {
+            hipKernelNodeParams kp;
+            memset(&kp, 0, sizeof kp);
+            if (hipGraphKernelNodeGetParams(nodes[i], &kp) != hipSuccess) { fprintf(f, "%zu kernel ?\n", i); continue; }
+            const char* nm = hipKernelNameRefByPtr(kp.func, nullptr);
+            fprintf(f, "%zu kernel %s grid %u,%u,%u block %u lds %u\n", i, nm ? nm : "?", kp.gridDim.x, kp.gridDim.y, kp.gridDim.z,
+                    kp.blockDim.x, kp.sharedMemBytes);
+        } else if (ty == hipGraphNodeTypeMemset) {
+            hipMemsetParams mp;
+            memset(&mp, 0, sizeof mp);
+            if (hipGraphMemsetNodeGetParams(nodes[i], &mp) != hipSuccess) { fprintf(f, "%zu memset ?\n", i); continue; }
+            fprintf(f, "%zu memset dst %p value %u elem %u width %zu height %zu\n", i, mp.dst, mp.value, mp.elementSize, mp.width, mp.height);
+        } else {
+            fprintf(f, "%zu type %d\n", i, (int)ty);
+        }
+    }
+    {   // dependency edges as index pairs
+        size_t ne = 0;
+        if (hipGraphGetEdges(graph, nullptr, nullptr, &ne) == hipSuccess && ne) {
+            std::vector<hipGraphNode_t> from(ne), to(ne);
+            if (hipGraphGetEdges(graph, from.data(), to.data(), &ne) == hipSuccess) {
+                auto idx = [&](hipGraphNode_t x) -> long { for (size_t i = 0; i < n; ++i) if (nodes[i] == x) return (long)i; return -1; };
+                fprintf(f, "edges %zu:", ne);
+                for (size_t e = 0; e < ne; ++e) fprintf(f, " %ld>%ld", idx(from[e]), idx(to[e]));
+                fprintf(f, "\n");
+            }
+        } else fprintf(f, "edges 0\n");
+    }
+    (void)hipGetLastError();
+    fclose(f);
+}
+
 static int pgd_iteration(vl_model* m, const float* x0, const int64_t* labels, int B, float eps, float alpha, float* adv,
                          hipStream_t s) {
     int rc = forward_impl(m, adv, B, 1, 0, s);
@@ -865,15 +911,12 @@ int vl_pgd_attack(vl_model* m, const float* x0, const int64_t* labels, int batch
             hipGraphExec_t exec = nullptr;
             for (GraphEntry& g : m->graphs)
                 if (g.B == batch && g.eps == eps && g.alpha == alpha) { exec = g.exec; break; }
-            int first = 0;
             if (!exec) {
-                // The iteration is run once EAGERLY before it is captured (it is the attack's first step, nothing is
-                // wasted): a kernel whose code object is first touched inside a stream capture did not make it into
-                // the graph reliably on ROCm 7.2 (replays then differed from the eager result until every kernel had
-                // been launched once outside capture; tools/determinism_probe2.py).
-                if ((rc = pgd_iteration(m, w.stage_x0, w.stage_labels, batch, eps, alpha, w.stage_adv, s))) return rc;
-                if ((rc = check_launch("vl_pgd_attack"))) return rc;
-                first = 1;
+                // Captured cold: nothing has to run eagerly first.  (Round 2 ran the first iteration eagerly because replays of
+                // a graph captured in a fresh process differed from the eager result.  Cause, established in round 3 with
+                // tools/cold_capture_diag.py: the two hipMemsetAsync nodes of the backward did not take effect on replays when
+                // they were captured before the runtime's fill kernel had ever run; the first launch passed only because the
+                // workspace was still zero.  They are k_zero kernel nodes now: profiles/r03_cold_capture_*.txt.)
                 hipGraph_t graph = nullptr;
                 // capture on a private stream (the caller's may be the legacy default stream, which cannot
                 // capture); nothing executes during capture, the graph is launched on the caller's stream.
@@ -884,6 +927,7 @@ int vl_pgd_attack(vl_model* m, const float* x0, const int64_t* labels, int batch
                 hipError_t e = hipStreamEndCapture(m->cap_stream, &graph);
                 if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
                 if (e != hipSuccess) return fail(VL_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+                dump_graph(graph);
                 e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
                 (void)hipGraphDestroy(graph);
                 if (e != hipSuccess) return fail(VL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
@@ -891,7 +935,7 @@ int vl_pgd_attack(vl_model* m, const float* x0, const int64_t* labels, int batch
                 m->graphs.push_back({batch, eps, alpha, exec});
                 m->n_captures++;
             }
-            for (int i = first; i < steps; ++i) HIPCHK(hipGraphLaunch(exec, s));
+            for (int i = 0; i < steps; ++i) HIPCHK(hipGraphLaunch(exec, s));
         }
     }
     HIPCHK(hipMemcpyAsync(adv_out, w.stage_adv, n * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1063,6 +1107,15 @@ int vl_check_gemm(int M, int N, int K1, int K2, int epi, int pp_mode, float* max
     return VL_OK;
 }
 
+// persistent-grid size of the GEMM kernels (and the batch threshold of the per-image attention form of `m`, if given):
+// experiments with two half-batch chains on disjoint halves of the chip (tools/dual_chain_probe.py)
+int vl_debug_set_cus(vl_model* m, int cus) {
+    if (cus <= 0) return fail(VL_ERR_ARG, "cus must be positive");
+    gemm256_set_cus(cus); gemm_pp_set_cus(cus);
+    if (m) m->num_cus = cus;
+    return VL_OK;
+}
+
 int vl_debug_set_gemm_pp(int mode) { const int old = gemm_pp_mode(); gemm_pp_set_mode(mode); return old; }
 
 // ---- profiling -------------------------------------------------------------------------------
@@ -1118,6 +1171,23 @@ int vl_debug_tensor(vl_model* m, const char* what, int layer, void** ptr, int64_
     Workspace& w = m->ws;
     if (!w.max_batch) return fail(VL_ERR_STATE, "no workspace");
     const int64_t MD = (int64_t)m->cur_B * m->T * m->D;
+    {   // backward-side buffers (shared across layers: they hold what the LAST executed kernel sequence left) and the head
+        const int64_t Mp = w.Mpad, img = (int64_t)m->cur_B * 3 * m->S * m->S;
+        struct { const char* name; void* p; int64_t n; int dt; } extra[] = {
+            {"dres0", w.dres[0], Mp * m->D, 0}, {"dres1", w.dres[1], Mp * m->D, 0}, {"grad_img", w.grad_img, img, 0},
+            {"stage_adv", w.stage_adv, img, 0}, {"stage_x0", w.stage_x0, img, 0},
+            {"logits", w.logits, (int64_t)m->cur_B * m->C, 0}, {"dlogits", w.dlogits, (int64_t)m->cur_B * m->C, 0},
+            {"gscale", w.gscale, m->cur_B, 0}, {"inv_gscale", w.inv_gscale, m->cur_B, 0}, {"loss_img", w.loss_img, m->cur_B, 0},
+            {"xhat", w.xhat, (int64_t)m->cur_B * m->D, 0}, {"rstd_f", w.rstd_f, m->cur_B, 0},
+            {"dres_h", m->f32 ? nullptr : w.dres_h, Mp * m->D, 1}, {"dh", m->f32 ? nullptr : w.dh, Mp * m->D, 1},
+            {"dctx", m->f32 ? nullptr : w.dctx, Mp * m->D, 1}, {"dqkv", m->f32 ? nullptr : w.dqkv, Mp * 3 * m->D, 1},
+            {"dz", m->f32 ? nullptr : w.dz, Mp * m->MLP, 1}, {"u", m->f32 ? nullptr : w.u, Mp * 64, 1}};
+        for (auto& e : extra)
+            if (!strcmp(what, e.name)) {
+                if (!e.p) return fail(VL_ERR_UNSUPPORTED, "%s: not in this precision mode", what);
+                *ptr = e.p; *numel = e.n; *dtype = e.dt; return VL_OK;
+            }
+    }
     if (!strcmp(what, "xs")) { if (layer < 0 || layer > 2 * m->L) return fail(VL_ERR_ARG, "index"); *ptr = w.xs[layer]; *numel = MD; *dtype = 0; return VL_OK; }
     if (layer < 0 || layer >= m->L) return fail(VL_ERR_ARG, "layer out of range");
     if (m->f32) {

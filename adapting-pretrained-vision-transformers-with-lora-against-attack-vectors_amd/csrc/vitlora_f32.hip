@@ -165,7 +165,7 @@ int f32_backward(vl_model* m, float* grad_x, float* flat_grad, hipStream_t s) {
         k_classifier_grad(w.dlogits, w.xf, B, D, m->C, flat_grad + m->cls_w_off, flat_grad + m->cls_b_off, s);
     }
     int cur = 0;
-    HIPCHK(hipMemsetAsync(w.dres[0], 0, (size_t)w.Mpad * D * sizeof(float), s));
+    k_zero(w.dres[0], (size_t)w.Mpad * D * sizeof(float), s);
     k_head_bwd(w.dlogits, nullptr, m->flat + m->cls_w_off, m->lnf_g, w.xhat, w.rstd_f, B, T, D, m->C, w.dres[0], nullptr, s);
     for (int l = L - 1; l >= 0; --l) {
         Layer& ly = m->layers[l];
