@@ -48,6 +48,20 @@ struct GemmArgs {
     uint64_t drop_seed; uint32_t drop_stream; float drop_p, drop_inv_keep;
 };
 
+// Algorithmic HBM bytes of `rows` output rows of a GEMM launch (profiling scopes; bench.py's traffic ratio divides the PMC
+// counter bytes by this): every operand element read once, every result element written once, in its storage type.
+static inline double gemm_algo_bytes(const GemmArgs& a, int epi, double rows) {
+    const double K = (double)a.K1 + (a.k2_algo ? a.k2_algo : a.K2);
+    const double N = a.n_algo ? a.n_algo : a.N;
+    double out = 2.0;                                   // h16 store
+    if (epi == EPI_RESID_F32) out = 8.0;                // read + write fp32
+    else if (epi == EPI_GELU) out = 4.0;                // gelu(z) and gelu'(z), h16 each
+    else if (epi == EPI_GELU_BWD) out = 4.0;            // read the saved gelu'(z), write h16
+    else if (epi == EPI_PATCH_FWD || epi == EPI_PATCH_BWD || epi == EPI_STORE_F32) out = 4.0;
+    else if (epi == EPI_NONE) out = 0.0;
+    return 2.0 * rows * K + 2.0 * N * K + rows * N * out + (a.down_W ? rows * 64 * 2.0 : 0.0);
+}
+
 // bn = 128 (default) or 64 (skinny LoRA-down GEMMs)
 void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s);
 int gemm_init(int device);

@@ -452,7 +452,8 @@ void launch_pp(const GemmArgs& a, hipStream_t s) {
     if (ND) snprintf(name, sizeof name, "gemm_pp_kernel<%d, down %d>", EPI, ND);
     else snprintf(name, sizeof name, "gemm_pp_kernel<%d>", EPI);
     const double valid = a.Mvalid ? (double)a.Mvalid / a.M : 1.0;
-    ProfScope prof_(name, 2.0 * a.M * valid * (a.n_algo ? a.n_algo : a.N) * (a.K1 + (a.k2_algo ? a.k2_algo : a.K2)), 0.0, s);
+    ProfScope prof_(name, 2.0 * a.M * valid * (a.n_algo ? a.n_algo : a.N) * (a.K1 + (a.k2_algo ? a.k2_algo : a.K2)),
+                    gemm_algo_bytes(a, EPI, a.M * valid), s);
     const int units = (ntiles + 1) / 2;
     const int grid = units < g_pp_cus ? (ntiles < g_pp_cus ? ntiles : g_pp_cus) : g_pp_cus;
     const size_t lds = (size_t)NSTAGE * stg_of(ND) * sizeof(h16) + 1024;

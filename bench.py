@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 PKG = "adapting-pretrained-vision-transformers-with-lora-against-attack-vectors_amd"
 
 PEAK_BF16_DENSE = 2.5e15      # FLOP/s dense (no sparsity), the bf16 / fp16 MFMA peak of MI355X_MICROARCH.md (same rate)
+PEAK_F32_MATRIX = 157.3e12    # FLOP/s, exact-f32 MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2), same guide
 PEAK_HBM = 8.0e12             # B/s
 
 EPS, ALPHA = 8 / 255, 2 / 255
@@ -182,30 +183,71 @@ def extras(P, syn, arch, args, dev, x, y):
                                                "batch": int(x.shape[0]), "pgd40_img_per_s": x.shape[0] / (40 * dts), "dtype": "f32"}
         log(f"extras: Swin-T + LoRA r=16 PGD step {1e3 * dts:.1f} ms at batch {x.shape[0]} (fp32)")
         del se, hf
+    if args.precision == "f16":
+        # the reference's own precision (whitebox_attacks.py:22-38 is fp32 end to end): the SAME PGD attack in the fp32 parity
+        # mode (every operand and activation fp32, exact-f32 MFMA), priced against the f32 matrix peak
+        e32 = P.Engine(arch, P.LoraSpec(r=args.rank, alpha=16.0, dropout=0.0, targets=TARGETS), device=dev, precision="f32")
+        e32.load_state_dict(syn.random_state_dict(arch, seed=0))
+        for (i, t), (A, Bm) in syn.random_lora(arch, args.rank, TARGETS, seed=1).items():
+            e32.param(i, t, "A").copy_(A)
+            e32.param(i, t, "B").copy_(Bm)
+        e32.commit()
+        adv32 = torch.empty_like(x)
+        e32.pgd_attack(x, y, EPS, ALPHA, 1, random_start=True, seed=1, out=adv32)       # graph capture, kernels loaded
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e32.pgd_attack(x, y, EPS, ALPHA, args.pgd_steps, random_start=True, seed=2, out=adv32)
+        torch.cuda.synchronize()
+        d32 = time.perf_counter() - t0
+        fl = algorithmic_flops_per_image_step(arch, args.rank, TARGETS)
+        tf = x.shape[0] / d32 * args.pgd_steps * fl / 1e12
+        res["fp32_mode"] = {"value": x.shape[0] / d32, "unit": "img/s", "ms_per_step": 1e3 * d32, "batch": int(x.shape[0]),
+                            "dtype": "f32", "tflops": tf, "peak_tflops": PEAK_F32_MATRIX / 1e12, "frac": tf * 1e12 / PEAK_F32_MATRIX,
+                            "what": f"the headline PGD-{args.pgd_steps} attack with precision=f32 (the reference's arithmetic)"}
+        log(f"extras: fp32 mode {x.shape[0] / d32:.1f} img/s ({tf:.1f} TFLOP/s)")
+        del e32, adv32
     res["lora_train_step"] = {"value": bt / dt, "unit": "img/s", "ms_per_step": 1e3 * dt, "batch": bt,
                               "what": "forward(train, dropout 0.1) + CE + LoRA/classifier backward + Adam, clean inputs"}
     log(f"extras: LoRA train step {1e3 * dt:.2f} ms at batch {bt}")
     return res
 
 
+_PMC = None
+
+
+def _pmc_table():
+    """The committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE per launch, tools/pmc_traffic.py; counters cannot be read
+    from inside this process).  The profile carries a hash of the kernel sources it was taken on: if the sources changed
+    since, every traffic number is OMITTED (None), never quoted stale."""
+    global _PMC
+    if _PMC is None:
+        _PMC = {}
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from pmc_traffic import kernel_source_sha16
+            t = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
+            if t.get("_meta", {}).get("kernel_source_sha16") == kernel_source_sha16():
+                _PMC = {k: v for k, v in t.items() if k != "_meta"}
+        except Exception:
+            _PMC = {}
+    return _PMC
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-    tools/pmc_traffic.py; counters cannot be read from inside this process).  The profile carries a hash of the
-    kernel sources it was taken on: if the sources changed since, the number is OMITTED (None), never quoted stale."""
-    try:
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        from pmc_traffic import kernel_source_sha16
-        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
-        if t.get("_meta", {}).get("kernel_source_sha16") != kernel_source_sha16():
-            return None
-        # the library's profiling scopes name the ping-pong GEMM "gemm_pp_kernel<EPI>" / "<EPI, down N>"; rocprofv3 reports the
-        # template arguments "<EPI, N>"
-        m = re.fullmatch(r"gemm_pp_kernel<(\d+)(?:, down (\d+))?>", kernel)
-        if m:
-            kernel = f"gemm_pp_kernel<{m.group(1)}, {m.group(2) or 0}>"
-        return t[kernel]["hbm_bytes_per_launch"]
-    except Exception:
+    """HBM bytes per launch of `kernel` (the library's profiling-scope name) or None."""
+    t = _pmc_table()
+    if not t:
         return None
+    # the library's scopes name the ping-pong GEMM "gemm_pp_kernel<EPI>" / "<EPI, down N>"; rocprofv3 reports "<EPI, N>"
+    m = re.fullmatch(r"gemm_pp_kernel<(\d+)(?:, down (\d+))?>", kernel)
+    if m:
+        kernel = f"gemm_pp_kernel<{m.group(1)}, {m.group(2) or 0}>"
+    if kernel in t:
+        return t[kernel]["hbm_bytes_per_launch"]
+    # scopes without template arguments (layernorm_fwd_kernel, attn_bwd_img_kernel ...): launch-weighted mean of the instances
+    inst = [v for k, v in t.items() if k.split("<")[0] == kernel]
+    n = sum(v["launches"] for v in inst)
+    return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in inst) / n if n else None
 
 
 T_START = time.perf_counter()
@@ -231,6 +273,39 @@ def host_cores():
     return int(os.environ.get("BENCH_CPU_CORES", min(n, 16)))   # a 1-GPU box's CPU share is 16
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (torch.distributed.run, one rank
+    per GPU over RCCL) before this process has touched the GPU, relay rank 0's JSON line and the child's exit code."""
+    import socket
+    import subprocess
+    if os.environ.get("BENCH_SHARE_GPU") != "1":
+        have = torch.cuda.device_count()          # does not initialise the GPU
+        if have < n:
+            print(f"[bench] --gpus {n} but only {have} device(s) visible: refusing to report a {n}-GPU number", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] starting", " ".join(cmd), file=sys.stderr, flush=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line:
+        print(line, flush=True)
+    elif rc == 0:
+        print("[bench] the ranks exited without a result line", file=sys.stderr)
+        rc = 3
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,8 +320,12 @@ def main():
     ap.add_argument("--vitl", action="store_true", help="extras: also time the attack on ViT-L/16 + LoRA r=16 at batch 128")
     ap.add_argument("--swin", action="store_true", help="extras: also time a PGD step of the Swin-T + LoRA r=16 path (fp32) at the bench batch")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (merged-LoRA attack, LoRA train step)")
+    ap.add_argument("--precision", choices=("f16", "f32"), default="f16",
+                    help="f16: fp16 operands / fp32 accumulation (the MFMA-rate path); f32: the reference's own precision (parity mode)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -262,14 +341,22 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if args.gpus != world:
+        if rank == 0:
+            print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
     dev = torch.device("cuda", local_rank)
+    ranks_seen = 1
+    if world > 1:
+        # the rank count the collective library itself saw (RCCL when backend = nccl)
+        one = torch.ones(1, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
 
     P = importlib.import_module(PKG)
     arch = P.ArchConfig(num_labels=21)
     spec = P.LoraSpec(r=args.rank, alpha=16.0, dropout=0.0, targets=TARGETS, merged=args.merged)
-    eng = P.Engine(arch, spec, device=dev)
+    eng = P.Engine(arch, spec, device=dev, precision=args.precision)
     syn = importlib.import_module(PKG + ".synthetic")
     eng.load_state_dict(syn.random_state_dict(arch, seed=0))
     for (i, t), (A, Bm) in syn.random_lora(arch, args.rank, TARGETS, seed=1).items():
@@ -314,13 +401,16 @@ def main():
         "metric": "adversarial images/sec (PGD-20, ViT-B/16+LoRA r=8, bs256)",
         "value": value, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": f"PGD-{args.pgd_steps} eps=8/255 alpha=2/255 random_start, ViT-B/16 (21 classes) + LoRA "
                                f"r={args.rank} on q,k,v,attn-out,fc2 ({'merged' if args.merged else 'fused'}), "
                                f"batch {args.batch}/GPU of synthetic 224x224x3 in HBM, seeded random-init weights",
                    "global_batch": world * args.batch, "pgd_steps": args.pgd_steps, "lora_rank": args.rank,
-                   "parallelism": f"dp{world} (batch shards, no data-path collective)"},
+                   "parallelism": f"dp{world} (batch shards, no data-path collective)",
+                   "ranks_seen_by_collective": ranks_seen,
+                   "collective_backend": (dist.get_backend() if world > 1 else None)},
     }
+    peak = PEAK_BF16_DENSE if args.precision == "f16" else PEAK_F32_MATRIX
 
     if rank == 0 and not args.no_roofline:
         lib = eng.lib
@@ -335,16 +425,38 @@ def main():
         d = prof[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
         ps = prof.get("pgd_step_kernel")
+        # every kernel that takes >= 1 % of the iteration: time, algorithmic work, fraction of the roof that bounds it, and
+        # counter traffic / algorithmic bytes (> 1 = re-reads); MFMA-bound when it has FLOPs and they, priced at the matrix
+        # peak, outweigh its bytes priced at the HBM peak
+        table = {}
+        for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+            if v["ms"] < 0.01 * tot_ms:
+                continue
+            t_s = v["ms"] * 1e-3
+            mf = v["flops"] / peak > v["bytes"] / PEAK_HBM
+            row = {"ms_per_pgd_iteration": round(v["ms"] / 2, 4), "launches_per_iteration": v["n"] // 2,
+                   "bound": "mfma" if mf else "hbm",
+                   "algorithmic_gflop_per_launch": round(v["flops"] / v["n"] / 1e9, 3),
+                   "algorithmic_mb_per_launch": round(v["bytes"] / v["n"] / 1e6, 2),
+                   "achieved": round(v["flops"] / t_s / 1e12, 1) if mf else round(v["bytes"] / t_s / 1e9, 1),
+                   "unit": "TFLOP/s" if mf else "GB/s",
+                   "frac": round((v["flops"] / t_s / peak) if mf else (v["bytes"] / t_s / PEAK_HBM), 4)}
+            tr = pmc_traffic(k)
+            row["traffic_mb_per_launch"] = None if tr is None else round(tr / 1e6, 1)
+            row["traffic_over_algorithmic"] = None if (tr is None or not v["bytes"]) else round(tr / (v["bytes"] / v["n"]), 3)
+            table[k] = row
         out["roofline"] = {
-            "bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
-            "frac": ach * 1e12 / PEAK_BF16_DENSE, "traffic": pmc_traffic(dom),
+            "bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak / 1e12, "unit": "TFLOP/s",
+            "frac": ach * 1e12 / peak, "traffic": pmc_traffic(dom),
             "launches": d["n"], "avg_launch_ms": d["ms"] / d["n"], "share_of_step_time": d["ms"] / tot_ms,
             "path": {"achieved": value * args.pgd_steps * flops_img_step / 1e12, "unit": "TFLOP/s",
-                     "frac": value * args.pgd_steps * flops_img_step / (world * PEAK_BF16_DENSE),
-                     "gflop_per_image_per_pgd_step": flops_img_step / 1e9},
+                     "frac": value * args.pgd_steps * flops_img_step / (world * peak),
+                     "gflop_per_image_per_pgd_step": flops_img_step / 1e9,
+                     "note": "algorithmic FLOPs of the reference's computation (SURVEY 8d), not the FLOPs executed"},
             "pgd_step": None if not ps else {
                 "bound": "hbm", "achieved": ps["bytes"] / (ps["ms"] * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9,
                 "unit": "GB/s", "frac": ps["bytes"] / (ps["ms"] * 1e-3) / PEAK_HBM, "avg_launch_ms": ps["ms"] / ps["n"]},
+            "kernels": table,
             "kernels_ms_per_pgd_iteration": {k: round(v["ms"] / 2, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
         }
 

@@ -211,16 +211,26 @@ def test_bench_contract_one_and_two_ranks():
     small = ["--steps", "1", "--warmup", "1", "--batch", "32", "--pgd-steps", "2", "--no-cpu-baseline", "--no-extras"]
     env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
     lines = {}
-    for n, launcher in ((1, [sys.executable]),
-                        (2, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                             "127.0.0.1", "--master-port", free_port()])):
-        r = subprocess.run(launcher + [os.path.join(root, "bench.py"), "--gpus", str(n)] + small, env=env, capture_output=True,
+    # n = 1; n = 2 under the driver's launcher; "self": plain `python bench.py --gpus 2`, which starts its own two ranks
+    for tag, n, launcher in ((1, 1, [sys.executable]),
+                             (2, 2, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                     "--master-addr", "127.0.0.1", "--master-port", free_port()]),
+                             ("self", 2, [sys.executable])):
+        e = dict(env)
+        if tag == "self":
+            e.pop("WORLD_SIZE", None)
+        r = subprocess.run(launcher + [os.path.join(root, "bench.py"), "--gpus", str(n)] + small, env=e, capture_output=True,
                            text=True, timeout=600)
-        assert r.returncode == 0, (n, r.stderr[-1500:])
+        assert r.returncode == 0, (tag, r.stderr[-1500:])
         js = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         assert len(js) == 1, r.stdout[-500:]
-        lines[n] = json.loads(js[0])
-    for n, d in lines.items():
+        lines[tag] = json.loads(js[0])
+    assert lines["self"]["n_gpus"] == 2 and lines["self"]["config"]["ranks_seen_by_collective"] == 2
+    assert lines[2]["config"]["ranks_seen_by_collective"] == 2 and lines[1]["config"]["ranks_seen_by_collective"] == 1
+    kt = lines[1]["roofline"]["kernels"]
+    assert kt and all(0.0 < v["frac"] < 1.0 and v["bound"] in ("mfma", "hbm") for v in kt.values())
+    for tag, d in lines.items():
+        n = 2 if tag == "self" else tag
         for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                     "vs_baseline", "dtype", "data", "config", "roofline"):
             assert key in d, (n, key)
