@@ -61,6 +61,13 @@ int k_attention_img_fwd(const h16* qkv, h16* ctx, float* lse2, int B, int T, int
 int k_attention_img_bwd(const h16* qkv, const h16* ctx, const h16* dctx, const float* lse2, h16* dqkv, int B, int T, int H,
                         int D, const h16* Bd, h16* u, int r, unsigned mods, hipStream_t s);
 
+// cls_path.hip: the last encoder layer on CLS rows only (compact [B, D] buffers)
+int k_attn_cls_fwd(const h16* qkv, h16* ctx_c, float* lse_c, int B, int T, int H, int D, hipStream_t s);
+int k_attn_cls_bwd(const h16* qkv, const h16* ctx_c, const h16* dctx_c, const float* lse_c, h16* dqkv, int B, int T, int H, int D,
+                   hipStream_t s);
+void k_gather_rows(const float* src, float* dst, int B, int D, int64_t stride, hipStream_t s);    // dst[b] = src[b * stride]
+void k_scatter_rows(const float* src, float* dst, int B, int D, int64_t stride, hipStream_t s);   // dst[b * stride] = src[b]
+
 // patch.hip: adversarial-patch overlay (warp-and-paste) and its gradient w.r.t. the patch
 void k_patch_overlay(const float* img, const float* patch, const float* mats, float* out, int B, int S, int ps, int circle,
                      hipStream_t s);

@@ -56,6 +56,14 @@ struct Workspace {
     h16 *dres_h, *dh, *dctx, *dqkv, *dz, *u;
     h16* xd;                         // train mode: dropout(x) of the current LoRA branch / dgrad temporary [Mpad, MLP]
     float* grad_img;                 // [max_batch, 3, S, S] for vl_pgd_attack
+    // last layer on CLS rows only (cls_path.hip): compact [Bc = round_up(B, 128), .] buffers, 16-bit operand path
+    struct Cls {
+        int64_t Bc = 0;
+        float *x0, *x1, *x2, *mean, *rstd, *lse;     // residual stream before attention / after attention / after the MLP
+        h16 *ctx, *delta, *h2, *a, *z, *t;
+        float* dres[2];
+        h16 *dres_h, *dh, *dctx, *dz, *u;
+    } c;
     // persistent staging of vl_pgd_attack: the captured graph only ever sees these addresses
     float *stage_x0, *stage_adv;
     int64_t* stage_labels;
@@ -101,6 +109,8 @@ struct vl_model {
     int plan_batch = 0, plan_train = 0;
     int attn_img_mode = -1;   // VITLORA_ATTN_IMG: 1 / 0 force the per-image attention kernels on / off, -1 = by batch size
     int num_cus = 256;
+    int dead_rows = 1;        // eval-mode forward / backward: last layer on CLS rows only (VITLORA_DEAD_ROWS=0 or vl_debug_set_dead_rows: off)
+    int cur_cls_only = 0;     // the last forward took that route
     int* err_flag = nullptr;                    // pinned host word written by kernels (bad label, ...), read at API entry
     float mean[3] = {0.485f, 0.456f, 0.406f};   // get_normalization, Utils.py:92-93
     float stdv[3] = {0.229f, 0.224f, 0.225f};

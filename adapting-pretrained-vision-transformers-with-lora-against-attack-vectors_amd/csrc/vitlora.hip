@@ -243,6 +243,7 @@ int vl_create(const vl_config* cfg, vl_model** out) {
     const char* ng = getenv("VITLORA_NO_GRAPH");
     m->use_graph = !(ng && ng[0] == '1');
     { const char* re = getenv("VITLORA_RESID"); m->resid_epi = (re && !strcmp(re, "epilogue")) ? 1 : 0; }
+    { const char* dr = getenv("VITLORA_DEAD_ROWS"); m->dead_rows = !(dr && dr[0] == '0'); }
     { const char* ai = getenv("VITLORA_ATTN_IMG"); m->attn_img_mode = ai ? (ai[0] == '1' ? 1 : 0) : -1; }
     { hipDeviceProp_t prop; m->num_cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256; }
     const int D = m->D, MLP = m->MLP, r = m->r;
@@ -520,6 +521,20 @@ static size_t carve(vl_model* m, int B, int train, char* base) {
         for (int k = 0; k < 4; ++k)
             w.t[k][l] = train ? (h16*)take((size_t)Mpad * kext_max * 2) : sh_t;
     }
+    {   // compact CLS-row buffers of the last layer
+        Workspace::Cls& c = w.c;
+        const int64_t Bc = round_up(B, 128);
+        c.Bc = Bc;
+        c.x0 = (float*)take((size_t)Bc * D * 4); c.x1 = (float*)take((size_t)Bc * D * 4); c.x2 = (float*)take((size_t)Bc * D * 4);
+        c.mean = (float*)take((size_t)Bc * 4); c.rstd = (float*)take((size_t)Bc * 4);
+        c.lse = (float*)take((size_t)B * m->H * 4);
+        c.ctx = (h16*)take((size_t)Bc * D * 2); c.delta = (h16*)take((size_t)Bc * D * 2); c.h2 = (h16*)take((size_t)Bc * D * 2);
+        c.a = (h16*)take((size_t)Bc * MLP * 2); c.z = (h16*)take((size_t)Bc * MLP * 2);
+        c.t = (h16*)take((size_t)Bc * kext_max * 2);
+        c.dres[0] = (float*)take((size_t)Bc * D * 4); c.dres[1] = (float*)take((size_t)Bc * D * 4);
+        c.dres_h = (h16*)take((size_t)Bc * D * 2); c.dh = (h16*)take((size_t)Bc * D * 2); c.dctx = (h16*)take((size_t)Bc * D * 2);
+        c.dz = (h16*)take((size_t)Bc * MLP * 2); c.u = (h16*)take((size_t)Bc * kext_max * 2);
+    }
     w.dres_h = (h16*)take((size_t)Mpad * D * 2);
     w.dh = (h16*)take((size_t)Mpad * D * 2);
     w.dctx = (h16*)take((size_t)Mpad * D * 2);
@@ -591,6 +606,9 @@ static int forward_impl(vl_model* m, const float* x, int B, int normalise, int t
     // 4 + 4 B/element read-modify-write in the GEMM epilogue, which the MFMA loop cannot hide)
     h16* delta = w.dres_h;                         // backward scratch, idle during the forward
     const bool re = m->resid_epi;
+    // eval-mode forwards only feed logits and input gradients: the last layer runs on the CLS rows alone
+    const bool cls_only = m->dead_rows && !train && !re;
+    m->cur_cls_only = 0;
     for (int l = 0; l < L; ++l) {
         Layer& ly = m->layers[l];
         GemmArgs g;
@@ -600,6 +618,29 @@ static int forward_impl(vl_model* m, const float* x, int B, int normalise, int t
         else k_layernorm_fwd(w.xs[2 * l - 1], w.h1[l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, ly.ln1_b, M, D, m->cfg.ln_eps, delta, w.xs[2 * l], P1, n1, w.t[LQKV][l], s);
         memset(&g, 0, sizeof g); g.C = w.qkv[l]; g.ldc = 3 * D;
         linear_fwd(m, ly.lin[LQKV], w.h1[l], w.t[LQKV][l], Mpad, g, EPI_STORE_H16, s, l * 4 + LQKV, n1 > 0);
+        if (cls_only && l == L - 1) {
+            // ---- last layer, CLS rows only (cls_path.hip): B rows from here to the classifier ----
+            Workspace::Cls& c = w.c;
+            const int Bc = (int)c.Bc;
+            if (k_attn_cls_fwd(w.qkv[l], c.ctx, c.lse, B, T, m->H, D, s)) return fail(VL_ERR_UNSUPPORTED, "attention: T > 256");
+            m->cur_M = B;                                          // rows the compact GEMMs may store
+            memset(&g, 0, sizeof g); g.C = c.delta; g.ldc = D;
+            linear_fwd(m, ly.lin[LO], c.ctx, c.t, Bc, g, EPI_STORE_H16, s, l * 4 + LO);
+            k_gather_rows(w.xs[2 * l], c.x0, B, D, (int64_t)T * D, s);
+            const int n2c = fused_down_fwd(m, ly.lin[LFC1]);
+            k_layernorm_fwd(c.x0, c.h2, c.mean, c.rstd, ly.ln2_g, ly.ln2_b, B, D, m->cfg.ln_eps, c.delta, c.x1,
+                            n2c ? ly.lin[LFC1].Ad : nullptr, n2c, c.t, s);
+            memset(&g, 0, sizeof g); g.C = c.a; g.ldc = m->MLP; g.C2 = c.z; g.ldc2 = m->MLP;
+            linear_fwd(m, ly.lin[LFC1], c.h2, c.t, Bc, g, EPI_GELU, s, l * 4 + LFC1, n2c > 0);
+            memset(&g, 0, sizeof g); g.C = c.delta; g.ldc = D;
+            linear_fwd(m, ly.lin[LFC2], c.a, c.t, Bc, g, EPI_STORE_H16, s, l * 4 + LFC2);
+            k_layernorm_fwd(c.x1, nullptr, nullptr, nullptr, nullptr, nullptr, B, D, m->cfg.ln_eps, c.delta, c.x2, nullptr, 0, nullptr, s);
+            m->cur_M = M;
+            k_head_fwd(c.x2, B, 1, D, m->C, m->cfg.ln_eps, m->lnf_g, m->lnf_b, m->flat + m->cls_w_off,
+                       m->flat + m->cls_b_off, w.xhat, w.xf, w.rstd_f, w.logits, s);
+            m->cur_B = B; m->cur_norm = normalise; m->cur_train = train; m->have_loss = 0; m->cur_cls_only = 1;
+            return VL_OK;
+        }
         // large batches: one persistent workgroup per image walks the heads; the LoRA down projection of the output
         // projection (t = ctx Ad^T) is summed over heads inside it, the skinny GEMM over ctx disappears
         const bool img = attn_img(m, B);
@@ -677,9 +718,13 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
         k_classifier_grad(w.dlogits, w.xf, B, D, m->C, flat_grad + m->cls_w_off, flat_grad + m->cls_b_off, s);
     }
     int cur = 0;
-    k_zero(w.dres[0], (size_t)Mpad * D * sizeof(float), s);       // kernel nodes, not memset nodes: section 3.3 of DESIGN.md
-    k_zero(w.dres_h, (size_t)Mpad * D * sizeof(h16), s);
-    k_head_bwd(w.dlogits, w.gscale, m->flat + m->cls_w_off, m->lnf_g, w.xhat, w.rstd_f, B, T, D, m->C, w.dres[0], w.dres_h, s);
+    const bool cls_only = m->cur_cls_only != 0;
+    if (cls_only && flat_grad) return fail(VL_ERR_STATE, "parameter gradients need a train-mode forward");
+    if (!cls_only) {
+        k_zero(w.dres[0], (size_t)Mpad * D * sizeof(float), s);       // kernel nodes, not memset nodes: section 3.3 of DESIGN.md
+        k_zero(w.dres_h, (size_t)Mpad * D * sizeof(h16), s);
+        k_head_bwd(w.dlogits, w.gscale, m->flat + m->cls_w_off, m->lnf_g, w.xhat, w.rstd_f, B, T, D, m->C, w.dres[0], w.dres_h, s);
+    }
 
     // LoRA weight gradients of one projection: dy [M,out], x [M,in], t/u [M,kext]
     auto wgrad = [&](const Linear& ln, const h16* dy, const h16* x, const h16* t, const h16* u, uint32_t stream_id) {
@@ -700,6 +745,33 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
     for (int l = L - 1; l >= 0; --l) {
         Layer& ly = m->layers[l];
         GemmArgs g;
+        if (cls_only && l == L - 1) {
+            // ---- last layer: the gradient lives on the CLS rows until dK / dV of the attention spread it over every token ----
+            Workspace::Cls& c = w.c;
+            const int Bc = (int)c.Bc;
+            m->cur_M = B;
+            k_head_bwd(w.dlogits, w.gscale, m->flat + m->cls_w_off, m->lnf_g, w.xhat, w.rstd_f, B, 1, D, m->C, c.dres[0], c.dres_h, s);
+            memset(&g, 0, sizeof g); g.C = c.dz; g.ldc = MLP; g.R = c.z; g.ldr = MLP;
+            linear_dgrad(m, ly.lin[LFC2], c.dres_h, c.u, Bc, g, EPI_GELU_BWD, s, l * 4 + LFC2);
+            memset(&g, 0, sizeof g); g.C = c.dh; g.ldc = D;
+            linear_dgrad(m, ly.lin[LFC1], c.dz, c.u, Bc, g, EPI_STORE_H16, s, l * 4 + LFC1);
+            const int foc = fused_down(m, ly.lin[LO]);
+            k_layernorm_bwd(c.dh, c.x1, c.mean, c.rstd, ly.ln2_g, c.dres[0], c.dres[1], c.dres_h, B, D, ly.lin[LO].Bd, foc, c.u, s);
+            memset(&g, 0, sizeof g); g.C = c.dctx; g.ldc = D;
+            linear_dgrad(m, ly.lin[LO], c.dres_h, c.u, Bc, g, EPI_STORE_H16, s, l * 4 + LO, foc > 0);
+            m->cur_M = M;
+            if (k_attn_cls_bwd(w.qkv[l], c.ctx, c.dctx, c.lse, w.dqkv, B, T, m->H, D, s)) return fail(VL_ERR_UNSUPPORTED, "attention: T > 256");
+            memset(&g, 0, sizeof g); g.C = w.dh; g.ldc = D;
+            linear_dgrad(m, ly.lin[LQKV], w.dqkv, w.u, Mpad, g, EPI_STORE_H16, s, l * 4 + LQKV);
+            // residual gradient entering LN1: zero except the CLS rows
+            k_zero(w.dres[cur], (size_t)Mpad * D * sizeof(float), s);
+            k_scatter_rows(c.dres[1], w.dres[cur], B, D, (int64_t)T * D, s);
+            const int ffc = l > 0 ? fused_down(m, m->layers[l - 1].lin[LFC2]) : 0;
+            k_layernorm_bwd(w.dh, w.xs[2 * l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, w.dres[cur], w.dres[cur ^ 1], w.dres_h,
+                            M, D, ffc ? m->layers[l - 1].lin[LFC2].Bd : nullptr, ffc, w.u, s);
+            cur ^= 1;
+            continue;
+        }
         // MLP: dz = (dx2 Wfc2 (+LoRA)) * gelu'(z)
         memset(&g, 0, sizeof g); g.C = w.dz; g.ldc = MLP; g.R = w.z[l]; g.ldr = MLP;
         // u of this dgrad came with dres_h from the LayerNorm backward of the layer above (not for the top layer)
@@ -1116,6 +1188,15 @@ int vl_debug_set_cus(vl_model* m, int cus) {
     return VL_OK;
 }
 
+// 1 (default): eval-mode forwards run the last layer on the CLS rows only; 0: every row of every layer (tests that read
+// the last layer's saved activations through vl_debug_tensor; A/B timing)
+int vl_debug_set_dead_rows(vl_model* m, int on) {
+    if (!m) return fail(VL_ERR_ARG, "null model");
+    m->dead_rows = on ? 1 : 0;
+    drop_graphs(m);
+    return VL_OK;
+}
+
 int vl_debug_set_gemm_pp(int mode) { const int old = gemm_pp_mode(); gemm_pp_set_mode(mode); return old; }
 
 // ---- profiling -------------------------------------------------------------------------------
@@ -1181,7 +1262,9 @@ int vl_debug_tensor(vl_model* m, const char* what, int layer, void** ptr, int64_
             {"xhat", w.xhat, (int64_t)m->cur_B * m->D, 0}, {"rstd_f", w.rstd_f, m->cur_B, 0},
             {"dres_h", m->f32 ? nullptr : w.dres_h, Mp * m->D, 1}, {"dh", m->f32 ? nullptr : w.dh, Mp * m->D, 1},
             {"dctx", m->f32 ? nullptr : w.dctx, Mp * m->D, 1}, {"dqkv", m->f32 ? nullptr : w.dqkv, Mp * 3 * m->D, 1},
-            {"dz", m->f32 ? nullptr : w.dz, Mp * m->MLP, 1}, {"u", m->f32 ? nullptr : w.u, Mp * 64, 1}};
+            {"dz", m->f32 ? nullptr : w.dz, Mp * m->MLP, 1}, {"u", m->f32 ? nullptr : w.u, Mp * 64, 1},
+            {"cls_x1", m->f32 ? nullptr : w.c.x1, (int64_t)m->cur_B * m->D, 0}, {"cls_x2", m->f32 ? nullptr : w.c.x2, (int64_t)m->cur_B * m->D, 0},
+            {"cls_ctx", m->f32 ? nullptr : w.c.ctx, (int64_t)m->cur_B * m->D, 1}};
         for (auto& e : extra)
             if (!strcmp(what, e.name)) {
                 if (!e.p) return fail(VL_ERR_UNSUPPORTED, "%s: not in this precision mode", what);

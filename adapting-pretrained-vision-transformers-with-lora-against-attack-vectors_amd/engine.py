@@ -186,6 +186,11 @@ class Engine:
         """The flat parameters were written through a view kept from earlier (self.flat, a broadcast, ...)."""
         check(self.lib.vl_params_changed(self.h), "vl_params_changed")
 
+    def set_dead_rows(self, on: bool):
+        """Eval-mode forwards compute the last encoder layer on the CLS rows only (default, exact: nothing else reaches the
+        classifier); off = every row of every layer (tests that read the last layer's saved activations)."""
+        check(self.lib.vl_debug_set_dead_rows(self.h, int(bool(on))), "vl_debug_set_dead_rows")
+
     def counter(self, what: str) -> int:
         v = C.c_int64()
         check(self.lib.vl_debug_counter(self.h, what.encode(), C.byref(v)), "vl_debug_counter")

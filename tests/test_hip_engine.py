@@ -36,6 +36,7 @@ def test_forward_stagewise(image_size, batch, with_lora, prec):
     cfg, w, lora, x, y = make_case(image_size=image_size, batch=batch, r=8 if with_lora else 0)
     eng = make_engine(cfg, w, lora, precision=prec)
     xn = O.normalise(x)
+    eng.set_dead_rows(False)            # every row of the last layer too: its saved activations are compared below
     logits = eng.forward(xn.cuda(), normalise=False)
     torch.cuda.synchronize()
     tr = _trace(cfg, w, lora, xn, sim=False)
@@ -55,6 +56,15 @@ def test_forward_stagewise(image_size, batch, with_lora, prec):
     if prec == "f16":       # kernel logic: against the oracle that rounds where the kernels round
         sim = _trace(cfg, w, lora, xn, sim=True)
         assert rel_l2(logits.cpu(), sim["logits"]) < TOL_SIM
+        # default route: the last layer on the CLS rows only -- same logits, and its CLS rows of the residual stream
+        eng.set_dead_rows(True)
+        logits2 = eng.forward(xn.cuda(), normalise=False)
+        torch.cuda.synchronize()
+        assert rel_l2(logits2.cpu(), logits.cpu()) < 5e-4 and rel_l2(logits2.cpu(), tr["logits"]) < TOL_ACT[prec]
+        L2 = 2 * cfg.layers
+        for name, ref in (("cls_x1", tr[f"xs{L2 - 1}"][:, 0]), ("cls_x2", tr[f"xs{L2}"][:, 0])):
+            got = eng.debug_tensor(name, 0).float().cpu().view(B, D)
+            assert rel_l2(got, ref) < TOL_ACT[prec], (name, rel_l2(got, ref))
 
 
 @pytest.mark.parametrize("prec", PRECS)
