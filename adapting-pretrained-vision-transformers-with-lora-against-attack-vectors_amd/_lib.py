@@ -65,7 +65,7 @@ SIGNATURES = {
     "vl_check_gemm": (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_float)]),
     "vl_debug_set_gemm_pp": (C.c_int, [C.c_int]),
     "vl_debug_set_cus": (C.c_int, [C.c_void_p, C.c_int]),
-    "vl_debug_set_dead_rows": (C.c_int, [C.c_void_p, C.c_int]),
+    "vl_debug_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "vl_profile_begin": (C.c_int, []),
     "vl_profile_report": (C.c_int, [C.c_char_p, C.c_size_t]),
     "vl_debug_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),

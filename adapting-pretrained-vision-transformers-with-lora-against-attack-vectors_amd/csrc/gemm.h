@@ -15,6 +15,7 @@ enum GemmEpilogue {
     EPI_STORE_F32 = 6,    // C(f32) = acc + bias
     EPI_NONE = 7,         // diagnostic: results kept live, nothing stored (timing of the main loop alone)
     EPI_DROP_ACC = 8,     // train-mode LoRA dgrad with dropout: C(h16) = (R(h16) + mask*acc) [* G(h16)]
+    EPI_PATCH_PGD = 9,    // EPI_PATCH_BWD's pixel gradient consumed in registers: C(f32) = adv <- clamp(x0 + clamp(adv + alpha sign(g) - x0, +-eps), lo, hi), R = x0
 };
 
 struct GemmArgs {
@@ -31,6 +32,7 @@ struct GemmArgs {
     const float* pos; int tokens; int patches; int grid; int psize; int img;
     float inv_std[3];
     const float* row_scale;   // EPI_PATCH_BWD: optional per-IMAGE factor (undoes the fp16 gradient scale), nullptr = 1
+    float pgd_eps, pgd_alpha, pgd_lo, pgd_hi;   // EPI_PATCH_PGD (K10 fused: whitebox_attacks.py:32-36 / the torchattacks PGD step)
     // A-row gather for the patch-embedding backward: GEMM row m = b*patches + p reads A row
     // b*tokens + 1 + p (the non-CLS rows of the token-major gradient); 0 = off
     int a_gather;
@@ -58,6 +60,7 @@ static inline double gemm_algo_bytes(const GemmArgs& a, int epi, double rows) {
     else if (epi == EPI_GELU) out = 4.0;                // gelu(z) and gelu'(z), h16 each
     else if (epi == EPI_GELU_BWD) out = 4.0;            // read the saved gelu'(z), write h16
     else if (epi == EPI_PATCH_FWD || epi == EPI_PATCH_BWD || epi == EPI_STORE_F32) out = 4.0;
+    else if (epi == EPI_PATCH_PGD) out = 12.0;           // read adv, x0; write adv
     else if (epi == EPI_NONE) out = 0.0;
     return 2.0 * rows * K + 2.0 * N * K + rows * N * out + (a.down_W ? rows * 64 * 2.0 : 0.0);
 }

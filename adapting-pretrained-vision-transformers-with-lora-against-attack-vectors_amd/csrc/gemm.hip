@@ -186,6 +186,7 @@ int gemm_init(int device) {
     set_attr<128, EPI_GELU_BWD>();
     set_attr<128, EPI_PATCH_FWD>();
     set_attr<128, EPI_PATCH_BWD>();
+    set_attr<128, EPI_PATCH_PGD>();
     set_attr<128, EPI_STORE_F32>();
     set_attr<128, EPI_DROP_ACC>();
     if (int e2 = gemm256_init()) g_attr_err = e2;
@@ -233,6 +234,7 @@ void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
         case EPI_GELU_BWD: launch_t<128, EPI_GELU_BWD>(a, s); break;
         case EPI_PATCH_FWD: launch_t<128, EPI_PATCH_FWD>(a, s); break;
         case EPI_PATCH_BWD: launch_t<128, EPI_PATCH_BWD>(a, s); break;
+        case EPI_PATCH_PGD: launch_t<128, EPI_PATCH_PGD>(a, s); break;
         case EPI_STORE_F32: launch_t<128, EPI_STORE_F32>(a, s); break;
         case EPI_DROP_ACC: launch_t<128, EPI_DROP_ACC>(a, s); break;
     }

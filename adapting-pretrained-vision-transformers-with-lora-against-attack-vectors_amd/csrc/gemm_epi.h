@@ -69,7 +69,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
             const f32x4 pe = *(const f32x4*)(p.pos + (size_t)(1 + pi) * p.ldc + n);
             *(f32x4*)((float*)p.C + ((size_t)b * p.tokens + 1 + pi) * p.ldc + n) = v + pe;
         }
-    } else if constexpr (EPI == EPI_PATCH_BWD) {
+    } else if constexpr (EPI == EPI_PATCH_BWD || EPI == EPI_PATCH_PGD) {
         if (m < p.Mvalid) {
             const int b = m / p.patches, pi = m - b * p.patches;
             const int py = pi / p.grid, px = pi - py * p.grid;
@@ -78,8 +78,21 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
             const int ph = rem / p.psize, pw = rem - ph * p.psize;
             const float s = p.inv_std[c] * (p.row_scale ? p.row_scale[b] : 1.f);
             f32x4 o = {v[0] * s, v[1] * s, v[2] * s, v[3] * s};
-            float* dst = (float*)p.C + (((size_t)b * 3 + c) * p.img + py * p.psize + ph) * p.img +
-                         px * p.psize + pw;
+            const size_t at = (((size_t)b * 3 + c) * p.img + py * p.psize + ph) * p.img + px * p.psize + pw;
+            float* dst = (float*)p.C + at;
+            if constexpr (EPI == EPI_PATCH_PGD) {
+                // K10 on the gradient while it is still in registers (the same fp32 operations as pgd_step_kernel, in the
+                // same order: bit-identical to the two-kernel form)
+                const f32x4 a = *(const f32x4*)dst;
+                const f32x4 x = *(const f32x4*)((const float*)p.R + at);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float sg = (o[k] > 0.f) ? 1.f : ((o[k] < 0.f) ? -1.f : 0.f);
+                    const float t = a[k] + p.pgd_alpha * sg;
+                    const float d = fminf(fmaxf(t - x[k], -p.pgd_eps), p.pgd_eps);
+                    o[k] = fminf(fmaxf(x[k] + d, p.pgd_lo), p.pgd_hi);
+                }
+            }
             *(f32x4*)dst = o;
         }
     }

@@ -244,6 +244,7 @@ int vl_create(const vl_config* cfg, vl_model** out) {
     m->use_graph = !(ng && ng[0] == '1');
     { const char* re = getenv("VITLORA_RESID"); m->resid_epi = (re && !strcmp(re, "epilogue")) ? 1 : 0; }
     { const char* dr = getenv("VITLORA_DEAD_ROWS"); m->dead_rows = !(dr && dr[0] == '0'); }
+    { const char* fp = getenv("VITLORA_FUSE_PGD"); m->fuse_pgd = !(fp && fp[0] == '0'); }
     { const char* ai = getenv("VITLORA_ATTN_IMG"); m->attn_img_mode = ai ? (ai[0] == '1' ? 1 : 0) : -1; }
     { hipDeviceProp_t prop; m->num_cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256; }
     const int D = m->D, MLP = m->MLP, r = m->r;
@@ -699,7 +700,10 @@ int vl_loss_ce(vl_model* m, const int64_t* labels, float* loss_out, void* stream
 // ---- backward --------------------------------------------------------------------------------
 // shared dgrad chain; flat_grad != null additionally produces the LoRA / classifier gradients,
 // grad_x != null the input gradient.
-static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream_t s) {
+// K10 fused into the patch-gradient epilogue: the pixel gradient never goes to HBM (vl_pgd_attack; vl_pgd_step stays the ABI entry)
+struct PgdFuse { float* adv; const float* x0; float eps, alpha; };
+
+static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream_t s, const PgdFuse* pf = nullptr) {
     Workspace& w = m->ws;
     if (!m->have_loss) return fail(VL_ERR_STATE, "backward before vl_loss_ce");
     const int B = m->cur_B, D = m->D, L = m->L, T = m->T, MLP = m->MLP, r = m->r;
@@ -806,14 +810,17 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
                         M, D, ff ? m->layers[l - 1].lin[LFC2].Bd : nullptr, ff, w.u, s);
         cur ^= 1;
     }
-    if (grad_x) {
+    if (grad_x || pf) {
         // d(pixels): patch rows of d(x0) times Wpe, scattered back to NCHW, chain rule of (x-mean)/std
         GemmArgs g = gemm_args(w.dres_h, D, m->WpeT, D, D, Mppad, m->PK);
         g.Mvalid = B * m->NP; g.C = grad_x; g.a_gather = 1;
         g.tokens = T; g.patches = m->NP; g.grid = m->G; g.psize = m->P; g.img = m->S;
         for (int c = 0; c < 3; ++c) g.inv_std[c] = m->cur_norm ? 1.f / m->stdv[c] : 1.f;
         g.row_scale = w.inv_gscale;          // per image: undoes the gradient scale
-        launch_gemm(g, EPI_PATCH_BWD, 128, s);
+        if (pf) {                            // sign -> alpha step -> eps projection -> clamp on the gradient in registers
+            g.C = pf->adv; g.R = pf->x0; g.pgd_eps = pf->eps; g.pgd_alpha = pf->alpha; g.pgd_lo = 0.f; g.pgd_hi = 1.f;
+            launch_gemm(g, EPI_PATCH_PGD, 128, s);
+        } else launch_gemm(g, EPI_PATCH_BWD, 128, s);
     }
     return VL_OK;
 }
@@ -950,6 +957,10 @@ static int pgd_iteration(vl_model* m, const float* x0, const int64_t* labels, in
     if (rc) return rc;
     k_ce_loss(m->ws.logits, labels, B, m->C, m->ws.dlogits, m->ws.loss_img, m->ws.loss, m->err_flag, s);
     m->have_loss = 1;
+    if (m->fuse_pgd && !m->f32) {
+        const PgdFuse pf = {adv, x0, eps, alpha};
+        return backward_impl(m, nullptr, nullptr, s, &pf);
+    }
     rc = backward_impl(m, m->ws.grad_img, nullptr, s);
     if (rc) return rc;
     k_pgd_step(adv, x0, m->ws.grad_img, eps, alpha, 0.f, 1.f, (int64_t)B * 3 * m->S * m->S, s);
@@ -1188,11 +1199,14 @@ int vl_debug_set_cus(vl_model* m, int cus) {
     return VL_OK;
 }
 
-// 1 (default): eval-mode forwards run the last layer on the CLS rows only; 0: every row of every layer (tests that read
-// the last layer's saved activations through vl_debug_tensor; A/B timing)
-int vl_debug_set_dead_rows(vl_model* m, int on) {
-    if (!m) return fail(VL_ERR_ARG, "null model");
-    m->dead_rows = on ? 1 : 0;
+// Diagnostic switches of a handle (tests, A/B timing); every change drops the cached PGD graphs.
+//   "dead_rows" 1 (default): eval-mode forwards run the last layer on the CLS rows only; 0: every row of every layer
+//   "fuse_pgd"  1 (default): vl_pgd_attack applies the PGD step inside the patch-gradient GEMM epilogue; 0: gradient to HBM + K10
+int vl_debug_set_option(vl_model* m, const char* name, int value) {
+    if (!m || !name) return fail(VL_ERR_ARG, "null argument");
+    if (!strcmp(name, "dead_rows")) m->dead_rows = value ? 1 : 0;
+    else if (!strcmp(name, "fuse_pgd")) m->fuse_pgd = value ? 1 : 0;
+    else return fail(VL_ERR_ARG, "unknown option %s", name);
     drop_graphs(m);
     return VL_OK;
 }

@@ -189,7 +189,11 @@ class Engine:
     def set_dead_rows(self, on: bool):
         """Eval-mode forwards compute the last encoder layer on the CLS rows only (default, exact: nothing else reaches the
         classifier); off = every row of every layer (tests that read the last layer's saved activations)."""
-        check(self.lib.vl_debug_set_dead_rows(self.h, int(bool(on))), "vl_debug_set_dead_rows")
+        self.set_option("dead_rows", on)
+
+    def set_option(self, name: str, value) -> None:
+        """Diagnostic switches of the handle ("dead_rows", "fuse_pgd": include/vitlora.h)."""
+        check(self.lib.vl_debug_set_option(self.h, name.encode(), int(value)), "vl_debug_set_option")
 
     def counter(self, what: str) -> int:
         v = C.c_int64()

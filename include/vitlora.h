@@ -250,7 +250,9 @@ int vl_bench_gemm(int M, int N, int K1, int K2, int epi, int bn, int iters, floa
 int vl_check_gemm(int M, int N, int K1, int K2, int epi, int pp_mode, float* max_diff);
 /* A/B switch of the ping-pong GEMM (same values as the environment variable VITLORA_GEMM_PP); returns the old mode. */
 int vl_debug_set_gemm_pp(int mode);
-int vl_debug_set_dead_rows(vl_model* m, int on);   /* 0: eval-mode forwards compute every row of the last layer too (default 1: CLS rows only) */
+/* Diagnostic switches of one handle: "dead_rows" (1: eval-mode forwards compute the last encoder layer on the CLS rows only,
+ * exact; 0: every row) and "fuse_pgd" (1: vl_pgd_attack applies K10 in the patch-gradient epilogue; 0: separate launch). */
+int vl_debug_set_option(vl_model* m, const char* name, int value);
 int vl_debug_set_cus(vl_model* m, int cus);   /* persistent GEMM grid size (diagnostic; default = the device's CU count) */
 
 /* Introspection for tests / profiling.  vl_debug_counter: "graph_captures" = PGD graphs captured so far,

@@ -106,9 +106,24 @@ def test_fgsm_is_pgd1_without_random_start(vitb):
     assert torch.equal(one, ref)
 
 
+def test_fused_pgd_step_equals_the_two_kernel_form(vitb):
+    """vl_pgd_attack applies K10 inside the patch-gradient GEMM epilogue (the pixel gradient never reaches HBM); with the
+    switch off the gradient is stored and pgd_step_kernel runs -- the same fp32 operations, so bit-identical results."""
+    eng, x, y = vitb
+    fused = eng.pgd_attack(x, y, EPS, ALPHA, 3, random_start=True, seed=5).clone()
+    eng.set_option("fuse_pgd", 0)
+    try:
+        split = eng.pgd_attack(x, y, EPS, ALPHA, 3, random_start=True, seed=5).clone()
+    finally:
+        eng.set_option("fuse_pgd", 1)
+    assert torch.equal(fused, split), (fused != split).float().mean().item()
+
+
 def test_first_attack_of_a_fresh_process_equals_its_replays():
-    """Regression (round 2): in a FRESH process whose first launches happen inside the stream capture, graph replays
-    differed from the first attack until the iteration was run once eagerly before capturing.  Needs its own process."""
+    """Regression (round 2 symptom, round 3 cause): in a FRESH process the PGD iteration is captured cold (nothing has run
+    eagerly before) and every replay must equal the first attack.  Two hipMemsetAsync nodes captured before the runtime's own
+    fill kernel had ever run used to be no-ops on replays (tools/cold_capture_diag.py; they are kernel nodes of the
+    library's code object now).  Needs its own process."""
     import os
     import subprocess
     import sys
