@@ -967,15 +967,402 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_bwd_img_kernel(const h16*
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Backward, single pass ("ring"): round 3.  attn_bwd_img_kernel above recomputes S, P, dP and dS twice per head (phase A with
+// the query on the lane for dQ, phase B with the key on the lane for dK / dV): 28 MFMAs and two exp blocks per 32 x 32 tile
+// pair.  Here each compute wave owns key block w AND query block w.  Step i of a head: the wave forms the tile
+// (queries (w+i) mod nb, keys w) ONCE with the key on the lane, accumulates its dK / dV, and hands the 32 x 32 dS tile
+// (h16, 2 KiB) to the owner of that query block through LDS; after the step's barrier it takes the tile another wave made for
+// ITS queries (keys (w-i) mod nb) and accumulates dQ += dS K: 20 MFMAs and one exp block per tile pair.  In one step every wave
+// writes a different slot (the ring), so the exchange needs no atomics, and two slot sets alternate so that one barrier per
+// step orders both the hand-over and the reuse.
+//   LDS: Q, dO of the head, K of this head and of the next (images of IR rows: T <= 200; reads past an image's end fall in
+//   the next image, or in the exchange slots behind the last one, which only ever hold finite h16 -- the products they
+//   enter are masked by P = 0 (queries >= T, LSE = +inf) or by zeroed dS (keys >= T)); exchange slots 2 x NT x 2 KiB;
+//   LSE / delta of the head and of the next; u sums; Bd slices.
+//   Loader wave: K of the next head during the steps, Q / dO of the next head under the compute waves' epilogue.
+// ------------------------------------------------------------------------------------------
+template <int NT> constexpr int ring_img_rows() { return NT == 7 ? 200 : NT * 32; }
+template <int NT>
+size_t bwd_ring_lds() {
+    return (size_t)4 * ring_img_rows<NT>() * HD * sizeof(h16) + (size_t)2 * NT * 2048 + (size_t)4 * NT * 32 * sizeof(float) +
+           (size_t)3 * NT * 32 * 8 * sizeof(float) + (size_t)2 * 3 * 8 * HD * sizeof(h16);
+}
+
+template <int NT>
+__global__ __launch_bounds__(64 * IMG_WAVES) void attn_bwd_ring_kernel(const h16* __restrict__ qkv, const h16* __restrict__ ctx,
+                                                                       const h16* __restrict__ dctx, const float* __restrict__ lse2,
+                                                                       h16* __restrict__ dqkv, int T, int H, int D, float scale,
+                                                                       float scale_log2e, const LoraDown lo) {
+    constexpr int ROWS = NT * 32, IR = ring_img_rows<NT>();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    h16* sQ = (h16*)smem;
+    h16* sdO = sQ + IR * HD;
+    h16* sK0 = sdO + IR * HD;                 // K of even / odd heads
+    char* sE = (char*)(sK0 + 2 * IR * HD);    // [2][NT][2048]: dS tiles, [key][query] h16, 64-byte rows, 8-byte chunk ch at ch ^ ((row>>2)&3)
+    float* sLD = (float*)(sE + 2 * NT * 2048);   // [2][2][ROWS]: {LSE, delta} by head parity
+    float* usum = sLD + 4 * ROWS;             // [3][ROWS][8]
+    h16* sBd = (h16*)(usum + 3 * ROWS * 8);   // [2][3][8][64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x;
+    const int ld = 3 * D;
+    const h16* base = qkv + (size_t)b * T * ld;
+    const h16* dobase = dctx + (size_t)b * T * D;
+    const h16* obase = ctx + (size_t)b * T * D;
+    const int nb = (T + 31) >> 5;
+
+    for (int i = tid; i < 3 * ROWS * 8; i += 64 * IMG_WAVES) usum[i] = 0.f;
+    for (int i = tid; i < 2 * NT * 2048 / 16; i += 64 * IMG_WAVES) ((f32x4*)sE)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Every wave executes the same barrier sequence: one after the prologue, then per head one per step and one at its end.
+    if (w == IMG_WAVES - 1) {
+        // ================================ LOADER ================================
+        // the head's [8][64] slices of Bd for query / key / value: requested early (bd_issue), stored to LDS a step later
+        // (bd_commit) -- a load that is used at once costs the loader a full memory round trip, and every wave waits for it
+        h16x8 bdv[3];
+        auto bd_issue = [&](int hd) {
+            const int j = lane >> 3, c8 = (lane & 7) * 8;
+#pragma unroll
+            for (int md = 0; md < 3; ++md) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) bdv[md][k] = (h16)0.f;
+                if (((lo.mods >> md) & 1u) && j < lo.r) bdv[md] = *(const h16x8*)(lo.W + (size_t)(md * lo.r + j) * ld + md * D + hd * HD + c8);
+            }
+        };
+        auto bd_commit = [&](int hd) {
+            const int j = lane >> 3, c8 = (lane & 7) * 8;
+            h16* dst = sBd + (hd & 1) * 3 * 8 * HD;
+#pragma unroll
+            for (int md = 0; md < 3; ++md) *(h16x8*)(dst + md * 8 * HD + j * HD + c8) = bdv[md];
+        };
+        // row constants of head hd for the 32 queries of block blk: LSE (rows >= T: +inf -> P = 0) and
+        // delta = rowsum(dO * O), each lane half sums 32 of the 64 features.  Split in two so that a block's loads are
+        // requested one step BEFORE they are used: a dependent global load under this kernel's own traffic takes longer
+        // than a whole step of the compute waves, and every wave meets the loader at the step's barrier.
+        h16x8 rd8[4], ro8[4];
+        float rlse = 0.f;
+        auto consts_issue = [&](int hd, int blk) {
+            const int t = blk * 32 + c, tc = t < T ? t : T - 1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                rd8[ks] = *(const h16x8*)(dobase + (size_t)tc * D + hd * HD + 8 * h + 16 * ks);
+                ro8[ks] = *(const h16x8*)(obase + (size_t)tc * D + hd * HD + 8 * h + 16 * ks);
+            }
+            rlse = lse2[((size_t)b * H + hd) * T + tc];
+        };
+        auto consts_finish = [&](int hd, int blk) {
+            const int t = blk * 32 + c;
+            float delta_q = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) delta_q = fmaf(h2f(rd8[ks][k]), h2f(ro8[ks][k]), delta_q);
+            delta_q += __shfl_xor(delta_q, 32, 64);
+            if (h == 0) {
+                float* Lw = sLD + (hd & 1) * 2 * ROWS;
+                Lw[t] = t < T ? rlse : INFINITY;
+                Lw[ROWS + t] = t < T ? delta_q : 0.f;
+            }
+        };
+        stage_glds<IR, 1>(sQ, base, ld, T, 0, lane);
+        stage_glds<IR, 1>(sdO, dobase, D, T, 0, lane);
+        stage_glds<IR, 1>(sK0, base + D, ld, T, 0, lane);
+        if (lo.W) {
+            h16x8 z;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) z[k] = (h16)0.f;
+            for (int i = lane; i < T * 8; i += 64) *(h16x8*)(lo.out + ((size_t)b * T + (i >> 3)) * 64 + (i & 7) * 8) = z;
+            bd_issue(0);
+            bd_commit(0);
+        }
+        for (int blk = 0; blk < NT; ++blk) { consts_issue(0, blk); consts_finish(0, blk); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LDS_BARRIER();
+#pragma unroll 1
+        for (int hd = 0; hd < H; ++hd) {
+            const bool more = hd + 1 < H;
+            ISTAMP(hd, 0);
+            if (more) {
+                consts_issue(hd + 1, 0);
+                if (lo.W) bd_issue(hd + 1);
+            }
+#pragma unroll 1
+            for (int i = 0; i < nb; ++i) {
+                if (i == 3) ISTAMP(hd, 1);
+                if (more) {                                                        // next head's constants, one block per step
+                    consts_finish(hd + 1, i);
+                    if (i == 0 && lo.W) bd_commit(hd + 1);
+                    if (i + 1 < NT) consts_issue(hd + 1, i + 1);
+                    // K of the next head goes out in slices, one per step, AFTER the next block's loads: with LDS-DMA in flight the
+                    // compiler drains the whole queue (vmcnt(0)) at the next use of an ordinary load, i.e. at the next step's
+                    // consts_finish -- a slice has had a whole step to land by then, the whole image at once had not
+                    {
+                        constexpr int NG = IR / 8;
+                        const int per = (NG + nb - 1) / nb;
+                        const int lr = lane >> 3, lc = lane & 7;
+                        h16* img = sK0 + ((hd + 1) & 1) * IR * HD;
+                        const h16* src = base + D + (hd + 1) * HD;
+                        for (int g = i * per; g < (i + 1) * per && g < NG; ++g) {
+                            const int r = g * 8 + lr;
+                            const int rs = r < T ? r : T - 1;
+                            glds16(src + (size_t)rs * ld + ((lc ^ swz(r)) << 3), img + g * 8 * HD);
+                        }
+                    }
+                }
+                if (i == nb - 1) {
+                    if (more) for (int blk = nb; blk < NT; ++blk) { consts_finish(hd + 1, blk); if (blk + 1 < NT) consts_issue(hd + 1, blk + 1); }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // K of the next head has landed
+                }
+                if (i == 3) ISTAMP(hd, 2);
+                LDS_BARRIER();
+                if (i == 3) ISTAMP(hd, 3);
+            }
+            ISTAMP(hd, 4);
+            if (more) {                                                            // Q / dO images are free after the last step's barrier
+                stage_glds<IR, 1>(sQ, base + (hd + 1) * HD, ld, T, 0, lane);
+                stage_glds<IR, 1>(sdO, dobase + (hd + 1) * HD, D, T, 0, lane);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ISTAMP(hd, 6);
+            LDS_BARRIER();
+            ISTAMP(hd, 7);
+        }
+        return;
+    }
+    if (w >= nb) {
+        // ================================ idle wave (T < 32 * NT): barriers only ================================
+        LDS_BARRIER();
+        for (int hd = 0; hd < H; ++hd) {
+            for (int i = 0; i < nb; ++i) LDS_BARRIER();
+            LDS_BARRIER();
+        }
+        return;
+    }
+    // ================================ COMPUTE: key block w and query block w ================================
+    const FragOffs fo = frag_offs(lane);
+    const int tok = w * 32 + c, tokc = tok < T ? tok : T - 1;
+    // exchange-slot offsets (bytes inside a 2 KiB slot).  Writer: own key = row c, queries 8*rq + 4*h + (0..3) = logical 8-byte
+    // chunk 2*rq + h, stored at chunk ^ ((c >> 2) & 3): ewr[rq & 1] + 32 * (rq >> 1).  Reader: transposed 4 x 16 blocks,
+    // rows 16*st + 4*(g>>1) + q4 + 8*e, logical chunk 4*(g&1) + p4: erd[e] + 1024 * st.
+    int ewr[2], erd[2];
+    {
+        const int f = (c >> 2) & 3;
+#pragma unroll
+        for (int r1 = 0; r1 < 2; ++r1) ewr[r1] = c * 64 + (((2 * r1 + h) ^ f) << 3);      // (2*rq + h) ^ f = ((2*(rq&1) + h) ^ f) + 4*(rq>>1): f < 4
+        const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int r = 4 * (g >> 1) + q4 + 8 * e;
+            erd[e] = r * 64 + (((4 * (g & 1) + p4) ^ ((r >> 2) & 3)) << 3);
+        }
+    }
+    h16x8 fb[4];                            // own v rows (B operand of dP); own k rows are re-read from the K image (registers are short)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fb[ks] = *(const h16x8*)(base + (size_t)tokc * ld + 2 * D + 8 * h + 16 * ks);
+    if (w >= 4) __builtin_amdgcn_s_setprio(1);
+    LDS_BARRIER();
+
+#pragma unroll 1
+    for (int hd = 0; hd < H; ++hd) {
+        const h16* sK = sK0 + (hd & 1) * IR * HD;
+        const float* L = sLD + (hd & 1) * 2 * ROWS;
+        const float* Dl = L + ROWS;
+        f32x16 dq[2], dk[2], dv[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dq[dt][r] = 0.f; dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+        // Software pipeline inside the wave: the matrix products that CONSUME a step's P / dS (dV, dK of the own keys; dQ of the
+        // own queries from the tile another wave handed over) are issued one step late, between the pieces of the next step's
+        // exp block -- they are independent of it, so the matrix pipe runs under the VALU work instead of before / after it.
+        // Step 0 runs them on zero operands.
+        h16x8 pbk[2], dsk[2];                 // P and dS of the previous step, packed (B operands of its dV / dK products)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { pbk[st][j] = (h16)0.f; dsk[st][j] = (h16)0.f; }
+        int qp = w, kp = w;                   // previous step's query tile (own keys) / key tile (own queries)
+        ISTAMP(hd, 0);
+        auto take_ds = [&](int step, int kt_, int st) -> h16x8 {      // the dS tile of step `step` made for the own queries, keys 16*st ..
+            const char* eslot = sE + ((step & 1) * NT + w) * 2048;
+            h16x8 d = cat4(lds_read_tr16(eslot + 1024 * st + erd[0]), lds_read_tr16(eslot + 1024 * st + erd[1]));
+            if (kt_ == nb - 1 && (T & 31)) {              // keys >= T of the partly filled tile contribute nothing
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (kt_ * 32 + 16 * st + 8 * (j >> 2) + 4 * h + (j & 3) >= T) d[j] = (h16)0.f;
+            }
+            return d;
+        };
+#pragma unroll 1
+        for (int i = 0; i < nb; ++i) {
+            int qt = w + i; if (qt >= nb) qt -= nb;
+            int kt = w - i; if (kt < 0) kt += nb;
+            if (i == 3) ISTAMP(hd, 1);
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s = mfma32(row_frag_o(sQ, qt, fo.row[ks]), row_frag_o(sK, w, fo.row[ks]), s);     // S[q][key]
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dp = mfma32(row_frag_o(sdO, qt, fo.row[ks]), fb[ks], dp);                         // dP[q][key]
+            // previous step's products ride in the four pieces of this step's exp block: piece 0, 1 -> dV, dK (key half st = 0, 1),
+            // piece 2, 3 -> dQ (st = 0, 1); the LDS fragments of piece n + 1 are requested before piece n's arithmetic
+            h16x8 fv0[2], fk0[2], fv1[2], fk1[2], fq0[2], fq1[2], d0, d1;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) { fv0[dt] = tr_frag_o(sdO, qp, 0, fo.tr[dt]); fk0[dt] = tr_frag_o(sQ, qp, 0, fo.tr[dt]); }
+            __builtin_amdgcn_sched_barrier(0);
+            auto exp_piece = [&](int rq) {
+                const f32x4 lq = *(const f32x4*)(L + qt * 32 + 8 * rq + 4 * h);
+                const f32x4 dl = *(const f32x4*)(Dl + qt * 32 + 8 * rq + 4 * h);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float p = fexp2(fmaf(s[4 * rq + k], scale_log2e, -lq[k]));   // rows >= T: 0
+                    s[4 * rq + k] = p;
+                    dp[4 * rq + k] = p * (dp[4 * rq + k] - dl[k]);
+                }
+            };
+            // piece 0
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) { fv1[dt] = tr_frag_o(sdO, qp, 1, fo.tr[dt]); fk1[dt] = tr_frag_o(sQ, qp, 1, fo.tr[dt]); }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) { dv[dt] = mfma32(fv0[dt], pbk[0], dv[dt]); dk[dt] = mfma32(fk0[dt], dsk[0], dk[dt]); }
+            exp_piece(0);
+            __builtin_amdgcn_sched_barrier(0);
+            // piece 1
+            d0 = take_ds(i + 1, kp, 0);                                                           // slot set of step i - 1
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) fq0[dt] = tr_frag_o(sK, kp, 0, fo.tr[dt]);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) { dv[dt] = mfma32(fv1[dt], pbk[1], dv[dt]); dk[dt] = mfma32(fk1[dt], dsk[1], dk[dt]); }
+            exp_piece(1);
+            __builtin_amdgcn_sched_barrier(0);
+            // piece 2
+            d1 = take_ds(i + 1, kp, 1);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) fq1[dt] = tr_frag_o(sK, kp, 1, fo.tr[dt]);
+            if (i == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { d0[j] = (h16)0.f; d1[j] = (h16)0.f; }
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(fq0[dt], d0, dq[dt]);                   // dQ^T[d][q]
+            exp_piece(2);
+            __builtin_amdgcn_sched_barrier(0);
+            // piece 3
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(fq1[dt], d1, dq[dt]);
+            exp_piece(3);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                char* eslot = sE + ((i & 1) * NT + qt) * 2048;
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    h16x4 o4;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o4[k] = f2h_sat(dp[4 * rq + k]);
+                    *(h16x4*)(eslot + ewr[rq & 1] + 32 * (rq >> 1)) = o4;
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) { pbk[st] = pack8(s, st); dsk[st] = pack8(dp, st); }
+            qp = qt; kp = kt;
+            if (i == nb - 1) {
+                // last step: its dV / dK cannot wait -- the loader overwrites the Q / dO images right after this step's barrier
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        dv[dt] = mfma32(tr_frag_o(sdO, qp, st, fo.tr[dt]), pbk[st], dv[dt]);
+                        dk[dt] = mfma32(tr_frag_o(sQ, qp, st, fo.tr[dt]), dsk[st], dk[dt]);
+                    }
+            }
+            if (i == 3) ISTAMP(hd, 2);
+            LDS_BARRIER();
+            if (i == 3) ISTAMP(hd, 3);
+        }
+        ISTAMP(hd, 4);
+        // drain the pipeline: the last step's dQ (K image and exchange slots stay valid until the end-of-head barrier)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const h16x8 d = take_ds(nb - 1, kp, st);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(tr_frag_o(sK, kp, st, fo.tr[dt]), d, dq[dt]);
+        }
+        // ---- head epilogue (the loader streams Q / dO of the next head meanwhile) ----
+        {
+            // (address arithmetic of this block derives from an opaque copy of the lane id: hoisted out of the head loop it
+            //  would occupy registers the step loop needs and spill)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int c2 = ln & 31, h2 = ln >> 5, tok2 = w * 32 + c2, tokc2 = tok2 < T ? tok2 : T - 1;
+            // next head's own v rows first: ahead of this head's stores in the wave's memory queue
+            if (hd + 1 < H) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) fb[ks] = *(const h16x8*)(base + (size_t)tokc2 * ld + 2 * D + (hd + 1) * HD + 8 * h2 + 16 * ks);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { dq[dt][r] *= scale; dk[dt][r] *= scale; }
+            if (lo.W) {
+                const h16* sB = sBd + (hd & 1) * 3 * 8 * HD;
+#pragma unroll
+                for (int md = 0; md < 3; ++md) {
+                    if (!((lo.mods >> md) & 1u)) continue;
+                    f32x16 y;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) y[r] = 0.f;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                        for (int st = 0; st < 2; ++st)
+                            y = mfma32(down_frag_lds(sB + md * 8 * HD, dt, st, ln), pack8(md == 0 ? dq[dt] : md == 1 ? dk[dt] : dv[dt], st), y);
+                    down_accumulate(usum + md * ROWS * 8, y, tok2, h2);
+                }
+            }
+            ISTAMP(hd, 5);
+            char* wimg = sE + ((nb & 1) * NT + w) * 2048;       // the slot set the last step did not use
+            h16* drow = dqkv + (size_t)b * T * ld + hd * HD;
+            store_rows32_half(wimg, dq, 1.f, drow, ld, w * 32, T, ln);
+            store_rows32_half(wimg, dk, 1.f, drow + D, ld, w * 32, T, ln);
+            store_rows32_half(wimg, dv, 1.f, drow + 2 * D, ld, w * 32, T, ln);
+        }
+        ISTAMP(hd, 6);
+        LDS_BARRIER();
+        ISTAMP(hd, 7);
+    }
+    if (lo.W && tok < T && 4 * h < lo.r) {
+        h16* dst = lo.out + ((size_t)b * T + tok) * 64 + 4 * h;
+#pragma unroll
+        for (int md = 0; md < 3; ++md) {
+            if (!((lo.mods >> md) & 1u)) continue;
+            const f32x4 u4 = *(const f32x4*)(usum + (md * ROWS + tok) * 8 + 4 * h);
+            h16x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = f2h(u4[k]);
+            *(h16x4*)(dst + md * lo.r) = v;
+        }
+    }
+}
+
 template <int NT>
 void launch_fwd_img(const h16* qkv, h16* ctx, float* lse2, int B, int T, int H, int D, const LoraDown& lo, hipStream_t s) {
     const float sl = 0.125f * 1.4426950408889634f;
     hipLaunchKernelGGL((attn_fwd_img_kernel<NT>), dim3(B), dim3(64 * IMG_WAVES), fwd_img_lds<NT>(), s, qkv, ctx, lse2, T, H, D, sl, lo);
 }
+int g_attn_ring = 1;      // VITLORA_ATTN_RING=0: the two-phase per-image backward (attn_bwd_img_kernel)
 template <int NT>
 void launch_bwd_img(const h16* qkv, const h16* ctx, const h16* dctx, const float* lse2, h16* dqkv, int B, int T, int H, int D,
                     const LoraDown& lo, hipStream_t s) {
     const float scale = 0.125f;
+    if (g_attn_ring && T <= ring_img_rows<NT>()) {
+        hipLaunchKernelGGL((attn_bwd_ring_kernel<NT>), dim3(B), dim3(64 * IMG_WAVES), bwd_ring_lds<NT>(), s, qkv, ctx, dctx, lse2, dqkv,
+                           T, H, D, scale, scale * 1.4426950408889634f, lo);
+        return;
+    }
     hipLaunchKernelGGL((attn_bwd_img_kernel<NT>), dim3(B), dim3(64 * IMG_WAVES), bwd_img_lds<NT>(), s, qkv, ctx, dctx, lse2, dqkv,
                        T, H, D, scale, scale * 1.4426950408889634f, lo);
 }
@@ -993,6 +1380,8 @@ void launch_bwd(const h16* qkv, const h16* ctx, const h16* dctx, const float* ls
 
 }  // namespace
 
+void attention32_set_ring(int on) { g_attn_ring = on ? 1 : 0; }
+
 int attention32_init(int device) {
     static bool done[64] = {};
     if (device < 0 || device >= 64) return -1;
@@ -1009,6 +1398,11 @@ int attention32_init(int device) {
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)attn_bwd_img_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_img_lds<7>());
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)attn_bwd_ring_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_ring_lds<1>());
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)attn_bwd_ring_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_ring_lds<7>());
+    if (e != hipSuccess) return (int)e;
+    if (const char* rg = getenv("VITLORA_ATTN_RING")) g_attn_ring = rg[0] != '0';
     done[device] = true;
     return 0;
 }

@@ -50,6 +50,7 @@ void k_merge_f32(const float* W, const float* A, const float* B, int out, int in
 
 
 // attention32.hip (32x32x16 MFMA)
+void attention32_set_ring(int on);   // 1: single-pass (ring) per-image backward, 0: two-phase form (process-wide)
 int attention32_init(int device);   // per-device kernel attributes (outside any stream capture); 0 = ok
 int k_attention32_fwd(const h16* qkv, h16* ctx, float* lse2, int B, int T, int H, int D, hipStream_t s);
 int k_attention32_bwd(const h16* qkv, const h16* ctx, const h16* dctx, const float* lse2, h16* dqkv, int B, int T,

@@ -1202,10 +1202,12 @@ int vl_debug_set_cus(vl_model* m, int cus) {
 // Diagnostic switches of a handle (tests, A/B timing); every change drops the cached PGD graphs.
 //   "dead_rows" 1 (default): eval-mode forwards run the last layer on the CLS rows only; 0: every row of every layer
 //   "fuse_pgd"  1 (default): vl_pgd_attack applies the PGD step inside the patch-gradient GEMM epilogue; 0: gradient to HBM + K10
+//   "attn_ring" 1 (default): single-pass per-image attention backward; 0: the two-phase form (process-wide switch)
 int vl_debug_set_option(vl_model* m, const char* name, int value) {
     if (!m || !name) return fail(VL_ERR_ARG, "null argument");
     if (!strcmp(name, "dead_rows")) m->dead_rows = value ? 1 : 0;
     else if (!strcmp(name, "fuse_pgd")) m->fuse_pgd = value ? 1 : 0;
+    else if (!strcmp(name, "attn_ring")) attention32_set_ring(value);        // process-wide
     else return fail(VL_ERR_ARG, "unknown option %s", name);
     drop_graphs(m);
     return VL_OK;
