@@ -12,11 +12,11 @@ Drop-in surface for the reference's hot path (whitebox_attacks.py / train_loras.
 
 Everything numeric runs in libvitlora_hip.so (include/vitlora.h); there is no CPU path.
 """
-from ._lib import LIB_PATH, VitLoraError, check  # noqa: F401
+from ._lib import LIB_PATH, NonFiniteGradient, VitLoraError, check  # noqa: F401
 from .engine import (IMAGENET_MEAN, IMAGENET_STD, ArchConfig, Engine, LoraSpec,  # noqa: F401
                      canonical_key, expected_keys, resolve_targets)
 
-__all__ = ["ArchConfig", "Engine", "LoraSpec", "VitLoraError", "LIB_PATH", "IMAGENET_MEAN", "IMAGENET_STD",
+__all__ = ["ArchConfig", "Engine", "LoraSpec", "VitLoraError", "NonFiniteGradient", "LIB_PATH", "IMAGENET_MEAN", "IMAGENET_STD",
            "resolve_targets", "canonical_key", "expected_keys"]
 
 

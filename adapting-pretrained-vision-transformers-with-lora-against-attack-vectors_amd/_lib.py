@@ -65,6 +65,7 @@ SIGNATURES = {
     "vl_check_gemm": (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_float)]),
     "vl_debug_set_gemm_pp": (C.c_int, [C.c_int]),
     "vl_debug_set_cus": (C.c_int, [C.c_void_p, C.c_int]),
+    "vl_check_errors": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vl_debug_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "vl_profile_begin": (C.c_int, []),
     "vl_profile_report": (C.c_int, [C.c_char_p, C.c_size_t]),
@@ -97,7 +98,12 @@ _lib = None
 
 
 class VitLoraError(RuntimeError):
-    pass
+    code = 0
+
+
+class NonFiniteGradient(VitLoraError):
+    """VL_ERR_NONFINITE: the fp16 backward left its range (or produced NaN) in an earlier call."""
+    code = -5
 
 
 def load():
@@ -122,4 +128,7 @@ def load():
 def check(rc: int, what: str = ""):
     if rc != 0:
         msg = load().vl_last_error().decode("utf-8", "replace")
-        raise VitLoraError(f"{what or 'vitlora call'} failed ({rc}): {msg}")
+        exc = NonFiniteGradient if rc == -5 else VitLoraError
+        e = exc(f"{what or 'vitlora call'} failed ({rc}): {msg}")
+        e.code = rc
+        raise e

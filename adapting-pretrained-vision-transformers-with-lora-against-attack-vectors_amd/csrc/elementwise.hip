@@ -183,9 +183,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const h16* __restric
                                                             const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                             const float* __restrict__ gamma, const float* __restrict__ dres,
                                                             float* __restrict__ dx, h16* __restrict__ dx_h, int M, int D,
-                                                            const h16* __restrict__ P, h16* __restrict__ u) {
+                                                            const h16* __restrict__ P, h16* __restrict__ u, int* __restrict__ err) {
     const int lane = threadIdx.x & 63;
     const int nv = D >> 2;
+    bool sat = false;          // a gradient that left the fp16 range (clamped by f2h_sat below) or is NaN: reported, never silent
     // with the fused projection a wave keeps its slice of P in registers and walks rows (grid-stride): P is read
     // once per wave, not once per row (per row it would double the kernel's L1 requests)
     LoraDownP<NV, NG ? NG : 1> pr;
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const h16* __restric
             for (int k = 0; k < 4; ++k) {
                 o[k] = r[k] + rstd * (g[i][k] - c1 - xh[i][k] * c2);
                 ob[k] = f2h_sat(o[k]);
+                sat |= !(fabsf(o[k]) <= 65504.f);
             }
             *(f32x4*)(dx + off + c * 4) = o;
             *(h16x4*)(dx_h + off + c * 4) = ob;
@@ -234,6 +236,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const h16* __restric
     // u = dx_h B of the projection whose dgrad consumes dx_h next (linear_dgrad skips its down GEMM)
     if constexpr (NG > 0) lora_down_row<NV, NG>(vb, pr, nv, lane, u + (int64_t)row * 64);
     }
+    if (sat && err) *err = 2;
 }
 
 // ---------------------------------------------------------------------------------
@@ -377,12 +380,13 @@ __device__ __forceinline__ float sgn(float g) { return (g > 0.f) ? 1.f : ((g < 0
 
 __global__ __launch_bounds__(256) void pgd_step_kernel(float* __restrict__ adv, const float* __restrict__ x0,
                                                        const float* __restrict__ grad, float eps, float alpha,
-                                                       float lo, float hi, int64_t n4, int64_t n) {
+                                                       float lo, float hi, int64_t n4, int64_t n, int* __restrict__ err) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
         const f32x4 a = *(const f32x4*)(adv + i * 4);
         const f32x4 x = *(const f32x4*)(x0 + i * 4);
         const f32x4 g = *(const f32x4*)(grad + i * 4);
+        if (err && !(fabsf(g[0]) < INFINITY && fabsf(g[1]) < INFINITY && fabsf(g[2]) < INFINITY && fabsf(g[3]) < INFINITY)) *err = 2;
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -435,10 +439,14 @@ __global__ void fill_random_h16_kernel(h16* __restrict__ dst, size_t n, uint64_t
 // K12: torch.optim.Adam single flat update (train_loras.py:284,315)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, float lr, float b1, float b2, float eps, float bc1,
-                            float sqrt_bc2, int64_t n) {
+                            float sqrt_bc2, int64_t n, int* __restrict__ err) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float gi = g[i];
+    if (!(fabsf(gi) < INFINITY)) {           // non-finite gradient: leave the parameter and its moments alone, report it
+        if (err) *err = 3;
+        return;
+    }
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi; v[i] = vi;
@@ -574,23 +582,23 @@ void k_layernorm_fwd(const float* x, h16* h, float* mean, float* rstd, const flo
 }
 template <int NV>
 static void launch_ln_bwd(dim3 grid, hipStream_t s, const h16* dh, const float* x, const float* mean, const float* rstd,
-                          const float* g, const float* dres, float* dx, h16* dx_h, int M, int D, const h16* P, int ng, h16* u) {
-    if (ng == 1) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 1>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u);
-    else if (ng == 2) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 2>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u);
-    else hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 0>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u);
+                          const float* g, const float* dres, float* dx, h16* dx_h, int M, int D, const h16* P, int ng, h16* u, int* err) {
+    if (ng == 1) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 1>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u, err);
+    else if (ng == 2) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 2>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u, err);
+    else hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 0>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u, err);
 }
 void k_layernorm_bwd(const h16* dh, const float* x, const float* mean, const float* rstd, const float* g,
-                     const float* dres, float* dx, h16* dx_h, int M, int D, const h16* P, int ng, h16* u, hipStream_t s) {
+                     const float* dres, float* dx, h16* dx_h, int M, int D, const h16* P, int ng, h16* u, hipStream_t s, int* err) {
     ProfScope prof_("layernorm_bwd_kernel", 0.0, (double)M * D * 16.0, s);
     const int nv = (D / 4 + 63) / 64;
     if (!P || !u || ng < 0 || ng > 2) ng = 0;
     dim3 grid((M + 3) / 4);
     if (ng && grid.x > 1024) grid.x = 1024;          // 4 resident blocks per CU walk the rows
     switch (nv) {
-        case 1: launch_ln_bwd<1>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, ng, u); break;
-        case 2: launch_ln_bwd<2>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, ng, u); break;
-        case 3: launch_ln_bwd<3>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, ng, u); break;
-        default: launch_ln_bwd<4>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, ng, u); break;
+        case 1: launch_ln_bwd<1>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, ng, u, err); break;
+        case 2: launch_ln_bwd<2>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, ng, u, err); break;
+        case 3: launch_ln_bwd<3>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, ng, u, err); break;
+        default: launch_ln_bwd<4>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, ng, u, err); break;
     }
 }
 void k_head_fwd(const float* x, int B, int T, int D, int C, float eps, const float* g, const float* b, const float* Wc,
@@ -651,11 +659,11 @@ void k_classifier_grad(const float* dlogits, const float* xf, int B, int D, int 
                        dW, db);
 }
 void k_pgd_step(float* adv, const float* x0, const float* grad, float eps, float alpha, float lo, float hi, int64_t n,
-                hipStream_t s) {
+                hipStream_t s, int* err) {
     ProfScope prof_("pgd_step_kernel", 0.0, (double)n * 16.0, s);
     const int64_t n4 = n / 4;
     hipLaunchKernelGGL(pgd_step_kernel, dim3(nblk(n4 > 0 ? n4 : 1, 256, 2048)), dim3(256), 0, s, adv, x0, grad, eps,
-                       alpha, lo, hi, n4, n);
+                       alpha, lo, hi, n4, n, err);
 }
 void k_zero(void* p, size_t bytes, hipStream_t s) {
     ProfScope prof_("zero_kernel", 0.0, (double)bytes, s);
@@ -667,11 +675,11 @@ void k_pgd_init(float* adv, const float* x0, float eps, float lo, float hi, uint
     hipLaunchKernelGGL(pgd_init_kernel, dim3(nblk(n, 256, 4096)), dim3(256), 0, s, adv, x0, eps, lo, hi, seed, n);
 }
 void k_adam(float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps, int t, int64_t n,
-            hipStream_t s) {
+            hipStream_t s, int* err) {
     ProfScope prof_("adam_kernel", 0.0, (double)n * 28.0, s);
     const float bc1 = 1.f - powf(b1, (float)t);
     const float sqrt_bc2 = sqrtf(1.f - powf(b2, (float)t));
-    hipLaunchKernelGGL(adam_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, p, g, m, v, lr, b1, b2, eps, bc1, sqrt_bc2, n);
+    hipLaunchKernelGGL(adam_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, p, g, m, v, lr, b1, b2, eps, bc1, sqrt_bc2, n, err);
 }
 void k_channel_affine(float* dst, const float* src, const float* scale, const float* shift, int B, int64_t hw,
                       hipStream_t s) {

@@ -32,6 +32,7 @@ struct GemmArgs {
     const float* pos; int tokens; int patches; int grid; int psize; int img;
     float inv_std[3];
     const float* row_scale;   // EPI_PATCH_BWD: optional per-IMAGE factor (undoes the fp16 gradient scale), nullptr = 1
+    int* err_flag;            // EPI_PATCH_BWD / EPI_PATCH_PGD: mapped host word, set to 2 when a pixel gradient is not finite (nullptr = unchecked)
     float pgd_eps, pgd_alpha, pgd_lo, pgd_hi;   // EPI_PATCH_PGD (K10 fused: whitebox_attacks.py:32-36 / the torchattacks PGD step)
     // A-row gather for the patch-embedding backward: GEMM row m = b*patches + p reads A row
     // b*tokens + 1 + p (the non-CLS rows of the token-major gradient); 0 = off

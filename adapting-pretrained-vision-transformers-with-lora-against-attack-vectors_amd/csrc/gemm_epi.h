@@ -78,6 +78,10 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
             const int ph = rem / p.psize, pw = rem - ph * p.psize;
             const float s = p.inv_std[c] * (p.row_scale ? p.row_scale[b] : 1.f);
             f32x4 o = {v[0] * s, v[1] * s, v[2] * s, v[3] * s};
+            // an fp16 backward that left its range shows up here as inf / NaN (the chain saturates or overflows upstream):
+            // never silent -- the next API call reports VL_ERR_NONFINITE (sign(NaN) = 0: that pixel does not move)
+            if (p.err_flag && !(fabsf(o[0]) < INFINITY && fabsf(o[1]) < INFINITY && fabsf(o[2]) < INFINITY && fabsf(o[3]) < INFINITY))
+                *p.err_flag = 2;
             const size_t at = (((size_t)b * 3 + c) * p.img + py * p.psize + ph) * p.img + px * p.psize + pw;
             float* dst = (float*)p.C + at;
             if constexpr (EPI == EPI_PATCH_PGD) {

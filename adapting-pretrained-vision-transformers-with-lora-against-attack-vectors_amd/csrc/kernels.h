@@ -15,7 +15,8 @@ void k_layernorm_fwd(const float* x, h16* h, float* mean, float* rstd, const flo
 // P / ng / u: optional fused LoRA down-projection of the h16 output row (u[row][0..63] = dx_h[row] . P[j], 8*ng rows
 // of P [>= 8*ng, D]; ng in {1, 2}; u has 64 columns), see lora_down_row in elementwise.hip
 void k_layernorm_bwd(const h16* dh, const float* x, const float* mean, const float* rstd, const float* g,
-                     const float* dres, float* dx, h16* dx_h, int M, int D, const h16* P, int ng, h16* u, hipStream_t s);
+                     const float* dres, float* dx, h16* dx_h, int M, int D, const h16* P, int ng, h16* u, hipStream_t s,
+                     int* err = nullptr);   // err: mapped host word, set to 2 when a gradient leaves the fp16 range / is NaN
 void k_head_fwd(const float* x, int B, int T, int D, int C, float eps, const float* g, const float* b, const float* Wc,
                 const float* bc, float* xhat, float* xf, float* rstd, float* logits, hipStream_t s);
 // err: mapped host word; set to 1 when a label is outside [0, C) (that image's loss / dlogits become NaN)
@@ -28,12 +29,14 @@ void k_grad_scale(const float* dlogits, int B, int C, int uniform, float* gscale
 void k_head_bwd(const float* dlogits, const float* gscale, const float* Wc, const float* g, const float* xhat,
                 const float* rstd, int B, int T, int D, int C, float* dx, h16* dx_h, hipStream_t s);
 void k_classifier_grad(const float* dlogits, const float* xf, int B, int D, int C, float* dW, float* db, hipStream_t s);
+// err (optional): mapped host word, set to 2 when a gradient element is not finite
 void k_pgd_step(float* adv, const float* x0, const float* grad, float eps, float alpha, float lo, float hi, int64_t n,
-                hipStream_t s);
+                hipStream_t s, int* err = nullptr);
 void k_zero(void* p, size_t bytes, hipStream_t s);   // bytes % 16 == 0; a kernel node, not a memset node, under capture
 void k_pgd_init(float* adv, const float* x0, float eps, float lo, float hi, uint64_t seed, int64_t n, hipStream_t s);
+// err (optional): set to 3 when a gradient element is not finite (that element is skipped)
 void k_adam(float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps, int t, int64_t n,
-            hipStream_t s);
+            hipStream_t s, int* err = nullptr);
 void k_channel_affine(float* dst, const float* src, const float* scale, const float* shift, int B, int64_t hw,
                       hipStream_t s);
 void k_fill_random_h16(h16* dst, size_t n, uint64_t seed, hipStream_t s);   // U(-1,1), benchmarks only

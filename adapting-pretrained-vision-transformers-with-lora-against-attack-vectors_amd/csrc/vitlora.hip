@@ -181,6 +181,10 @@ int check_async(vl_model* m) {
         const int code = *m->err_flag;
         *m->err_flag = 0;
         if (code == 1) return fail(VL_ERR_ARG, "a label passed to an earlier vl_loss_ce / vl_pgd_attack was outside [0, num_labels)");
+        if (code == 2) return fail(VL_ERR_NONFINITE, "an earlier backward pass produced a non-finite input gradient (fp16 range exceeded): "
+                                   "redo that batch with precision = f32");
+        if (code == 3) return fail(VL_ERR_NONFINITE, "an earlier vl_adam_step saw a non-finite parameter gradient (those elements were "
+                                   "skipped): drop that step or redo it with precision = f32");
         return fail(VL_ERR_HIP, "device-side error flag %d", code);
     }
     return VL_OK;
@@ -760,7 +764,7 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
             memset(&g, 0, sizeof g); g.C = c.dh; g.ldc = D;
             linear_dgrad(m, ly.lin[LFC1], c.dz, c.u, Bc, g, EPI_STORE_H16, s, l * 4 + LFC1);
             const int foc = fused_down(m, ly.lin[LO]);
-            k_layernorm_bwd(c.dh, c.x1, c.mean, c.rstd, ly.ln2_g, c.dres[0], c.dres[1], c.dres_h, B, D, ly.lin[LO].Bd, foc, c.u, s);
+            k_layernorm_bwd(c.dh, c.x1, c.mean, c.rstd, ly.ln2_g, c.dres[0], c.dres[1], c.dres_h, B, D, ly.lin[LO].Bd, foc, c.u, s, m->err_flag);
             memset(&g, 0, sizeof g); g.C = c.dctx; g.ldc = D;
             linear_dgrad(m, ly.lin[LO], c.dres_h, c.u, Bc, g, EPI_STORE_H16, s, l * 4 + LO, foc > 0);
             m->cur_M = M;
@@ -772,7 +776,7 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
             k_scatter_rows(c.dres[1], w.dres[cur], B, D, (int64_t)T * D, s);
             const int ffc = l > 0 ? fused_down(m, m->layers[l - 1].lin[LFC2]) : 0;
             k_layernorm_bwd(w.dh, w.xs[2 * l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, w.dres[cur], w.dres[cur ^ 1], w.dres_h,
-                            M, D, ffc ? m->layers[l - 1].lin[LFC2].Bd : nullptr, ffc, w.u, s);
+                            M, D, ffc ? m->layers[l - 1].lin[LFC2].Bd : nullptr, ffc, w.u, s, m->err_flag);
             cur ^= 1;
             continue;
         }
@@ -786,7 +790,7 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
         wgrad(ly.lin[LFC1], w.dz, w.h2[l], w.t[LFC1][l], w.u, l * 4 + LFC1);
         const int fo = fused_down(m, ly.lin[LO]);
         k_layernorm_bwd(w.dh, w.xs[2 * l + 1], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, w.dres[cur], w.dres[cur ^ 1],
-                        w.dres_h, M, D, ly.lin[LO].Bd, fo, w.u, s);
+                        w.dres_h, M, D, ly.lin[LO].Bd, fo, w.u, s, m->err_flag);
         cur ^= 1;
         // attention block
         memset(&g, 0, sizeof g); g.C = w.dctx; g.ldc = D;
@@ -807,7 +811,7 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
         wgrad(ly.lin[LQKV], w.dqkv, w.h1[l], w.t[LQKV][l], w.u, l * 4 + LQKV);
         const int ff = l > 0 ? fused_down(m, m->layers[l - 1].lin[LFC2]) : 0;     // next consumer: fc2 dgrad of the layer below
         k_layernorm_bwd(w.dh, w.xs[2 * l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, w.dres[cur], w.dres[cur ^ 1], w.dres_h,
-                        M, D, ff ? m->layers[l - 1].lin[LFC2].Bd : nullptr, ff, w.u, s);
+                        M, D, ff ? m->layers[l - 1].lin[LFC2].Bd : nullptr, ff, w.u, s, m->err_flag);
         cur ^= 1;
     }
     if (grad_x || pf) {
@@ -817,12 +821,21 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
         g.tokens = T; g.patches = m->NP; g.grid = m->G; g.psize = m->P; g.img = m->S;
         for (int c = 0; c < 3; ++c) g.inv_std[c] = m->cur_norm ? 1.f / m->stdv[c] : 1.f;
         g.row_scale = w.inv_gscale;          // per image: undoes the gradient scale
+        g.err_flag = m->err_flag;
         if (pf) {                            // sign -> alpha step -> eps projection -> clamp on the gradient in registers
             g.C = pf->adv; g.R = pf->x0; g.pgd_eps = pf->eps; g.pgd_alpha = pf->alpha; g.pgd_lo = 0.f; g.pgd_hi = 1.f;
             launch_gemm(g, EPI_PATCH_PGD, 128, s);
         } else launch_gemm(g, EPI_PATCH_BWD, 128, s);
     }
     return VL_OK;
+}
+
+// Synchronises `stream` and reports what the kernels enqueued so far flagged (bad label: VL_ERR_ARG; a gradient that left the
+// fp16 range or is NaN: VL_ERR_NONFINITE).  Other entry points report the same at their NEXT call without synchronising.
+int vl_check_errors(vl_model* m, void* stream) {
+    if (!m) return fail(VL_ERR_ARG, "null model");
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return fail(VL_ERR_HIP, "hipStreamSynchronize failed");
+    return check_async(m);
 }
 
 int vl_set_dlogits(vl_model* m, const float* dlogits, void* stream) {
@@ -963,7 +976,7 @@ static int pgd_iteration(vl_model* m, const float* x0, const int64_t* labels, in
     }
     rc = backward_impl(m, m->ws.grad_img, nullptr, s);
     if (rc) return rc;
-    k_pgd_step(adv, x0, m->ws.grad_img, eps, alpha, 0.f, 1.f, (int64_t)B * 3 * m->S * m->S, s);
+    k_pgd_step(adv, x0, m->ws.grad_img, eps, alpha, 0.f, 1.f, (int64_t)B * 3 * m->S * m->S, s, m->err_flag);
     return VL_OK;
 }
 
@@ -1028,9 +1041,10 @@ int vl_pgd_attack(vl_model* m, const float* x0, const int64_t* labels, int batch
 int vl_adam_step(float* param, const float* grad, float* m1, float* m2, float lr, float b1, float b2, float eps, int t,
                  int64_t n, void* stream) {
     if (!param || !grad || !m1 || !m2 || n <= 0 || t <= 0) return fail(VL_ERR_ARG, "bad argument");
-    k_adam(param, grad, m1, m2, lr, b1, b2, eps, t, n, (hipStream_t)stream);
+    int* err = nullptr;
     for (vl_model* mm : g_models)      // optimizer.step() on a model's flat parameters: its operands are stale now
-        if (param < mm->flat + mm->flat_n && param + n > mm->flat) mm->dirty = 1;
+        if (param < mm->flat + mm->flat_n && param + n > mm->flat) { mm->dirty = 1; err = mm->err_flag; }
+    k_adam(param, grad, m1, m2, lr, b1, b2, eps, t, n, (hipStream_t)stream, err);
     return VL_OK;
 }
 

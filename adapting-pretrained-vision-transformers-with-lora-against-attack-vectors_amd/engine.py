@@ -195,6 +195,11 @@ class Engine:
         """Diagnostic switches of the handle ("dead_rows", "fuse_pgd": include/vitlora.h)."""
         check(self.lib.vl_debug_set_option(self.h, name.encode(), int(value)), "vl_debug_set_option")
 
+    def check(self):
+        """Synchronise the current stream and raise what the kernels flagged: VitLoraError (bad label) or
+        _lib.NonFiniteGradient (fp16 mode: a gradient left the fp16 range -- skip that step or redo the batch in f32)."""
+        check(self.lib.vl_check_errors(self.h, self._stream()), "vl_check_errors")
+
     def counter(self, what: str) -> int:
         v = C.c_int64()
         check(self.lib.vl_debug_counter(self.h, what.encode(), C.byref(v)), "vl_debug_counter")

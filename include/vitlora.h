@@ -30,6 +30,7 @@ extern "C" {
 #define VL_ERR_HIP (-2)
 #define VL_ERR_STATE (-3)
 #define VL_ERR_UNSUPPORTED (-4)
+#define VL_ERR_NONFINITE (-5)   /* an EARLIER call produced a non-finite gradient (fp16 range exceeded): that step must be skipped / redone in f32 */
 
 /* LoRA target bits.  peft matches module-name suffixes: the reference's
  * ["query","key","value","output.dense"] (train_loras.py:81) = Q|K|V|O|FC2. */
@@ -237,6 +238,12 @@ int vl_swin_pgd_attack(vl_swin* m, const float* x0, const int64_t* labels, int b
  * pair (PGD runs eagerly, not as a graph, while active).  report synchronises the device and
  * writes a JSON object {"<kernel>": {"n": launches, "ms": total, "flops": algorithmic,
  * "bytes": algorithmic}, ...} into buf. */
+/* Synchronises `stream` and returns the error kernels have flagged since the last check: VL_ERR_ARG (label outside
+ * [0, num_labels)), VL_ERR_NONFINITE (fp16 mode: a gradient left the fp16 range or is NaN; the caller skips that step or
+ * redoes the batch with precision = f32 -- what an AMP skip-step does; torch autograd in the reference is fp32 and has no
+ * counterpart).  Every other entry point reports the same condition at its next call, without synchronising. */
+int vl_check_errors(vl_model* m, void* stream);
+
 int vl_profile_begin(void);
 int vl_profile_report(char* buf, size_t cap);
 

@@ -13,6 +13,7 @@ import pytest
 import torch
 
 from helpers import O, make_case, make_engine, rel_l2
+from helpers import pkg as pkg_mod
 
 pytestmark = pytest.mark.gpu
 
@@ -125,6 +126,42 @@ def test_other_widths_run_the_256_row_gemm(hidden, heads, mlp, layers, r, prec):
     assert rel_l2(gx.cpu(), g_ref) < TOL_GRAD[prec]
     big = g_ref.abs() > 0.05 * g_ref.abs().mean()
     assert (torch.sign(gx.cpu())[big] == torch.sign(g_ref)[big]).float().mean().item() > 0.9995
+
+
+@pytest.mark.parametrize("gain", [4.0, 32.0, 512.0])
+def test_fp16_backward_out_of_range_is_flagged_never_silent(gain):
+    """Round-2 ADVICE: every parity fixture has unit-gain weights, a fine-tuned checkpoint need not.  LayerNorm gains and the
+    classifier scaled by `gain` amplify the backward chain per layer; the fp16 path must then EITHER stay finite and accurate
+    (the per-image power-of-two gradient scale absorbs the classifier factor) OR report VL_ERR_NONFINITE at the next check --
+    a clamped (f2h_sat), infinite or NaN gradient that goes unreported is the failure this test exists for."""
+    P = pkg_mod()
+    cfg, w, lora, x, y = make_case(image_size=64, batch=4, r=8, layers=4)
+    w2 = {k: (v * gain if (k.endswith("layernorm_before.weight") or k.endswith("layernorm_after.weight") or k == "classifier.weight")
+              else v) for k, v in w.items()}
+    eng = make_engine(cfg, w2, lora, precision="f16")
+    eng.forward(x.cuda(), normalise=True)
+    eng.loss_ce(y.cuda())
+    gx, _ = eng.backward(True, False, tuple(x.shape))
+    flagged = False
+    try:
+        eng.check()
+    except P.NonFiniteGradient:
+        flagged = True
+    _, g_ref, _ = O.loss_and_input_grad(w2, cfg, x, y, lora)
+    if not flagged:
+        assert torch.isfinite(gx).all()
+        assert rel_l2(gx.cpu(), g_ref) < 2 * TOL_GRAD["f16"], (gain, rel_l2(gx.cpu(), g_ref))
+    if gain >= 512.0:
+        assert flagged, "a 512x gain per LayerNorm over 4 layers cannot fit fp16: the overflow must be reported"
+        # the fp32 mode is the documented way out and has the range
+        e32 = make_engine(cfg, w2, lora, precision="f32")
+        e32.forward(x.cuda(), normalise=True)
+        e32.loss_ce(y.cuda())
+        g32, _ = e32.backward(True, False, tuple(x.shape))
+        e32.check()
+        assert rel_l2(g32.cpu(), g_ref) < 10 * TOL_GRAD["f32"]
+    # the flag is cleared by reading it: the engine is usable again
+    eng.check()
 
 
 def test_ragged_batches_replanning_and_empty_input():

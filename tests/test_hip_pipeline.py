@@ -172,6 +172,44 @@ def test_two_rank_lora_training_equals_single_process(tmp_path):
         assert len(r1[k4][key]) == 2 and np.allclose(r1[k4][key], r2[k4][key], atol=tol), (key, r1[k4][key], r2[k4][key])
 
 
+_FAIL_WORKER = r'''
+import os, sys
+sys.path.insert(0, {root!r})
+import train_loras as TL
+rank = int(os.environ["RANK"])
+orig = TL.opt.Adam.step
+calls = [0]
+def step(self, *a, **k):
+    calls[0] += 1
+    if rank == 1 and calls[0] == 2:
+        raise RuntimeError("injected failure on rank 1, before its all-reduce")
+    return orig(self, *a, **k)
+TL.opt.Adam.step = step
+TL.main(["--output_dir", {out!r}, "--synthetic", "40", "--arch", "tiny", "--attacks", "fgsm", "--ranks", "4", "--epochs", "2",
+         "--batch_size", "16", "--lora_dropout", "0", "--num_classes", "5"])
+'''
+
+
+def test_one_sided_failure_ends_the_job_instead_of_desynchronising_it(tmp_path):
+    """Round-2 ADVICE: rank 1 raises in the middle of the step loop while rank 0 is inside (or on its way to) the gradient
+    all-reduce.  The failing rank must not enter any collective from its failure path (the old all_ok() all-reduce would have
+    paired up with rank 0's gradient exchange); it exits non-zero at once and the job ends -- no hang, no success code."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "fail_worker.py"
+    script.write_text(_FAIL_WORKER.format(root=root, out=str(tmp_path / "out")))
+    env = dict(os.environ, VITLORA_SHARE_GPU="1", VITLORA_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", free_port(), str(script)], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0, r.stdout[-1500:]
+    assert "injected failure on rank 1" in (r.stdout + r.stderr)
+    assert time.time() - t0 < 200
+    assert not os.path.exists(os.path.join(str(tmp_path / "out"), "global_results.json"))
+
+
 def test_two_rank_patch_attack_cli(tmp_path):
     """patch_attack.py --synthetic under `torch.distributed.run` with two ranks (one shared GPU, gloo): shards of every global
     batch, ONE shard-size-weighted all-reduce of the patch gradient per step, batches of the split patched round-robin, rank 0

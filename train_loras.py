@@ -93,11 +93,6 @@ class Dist:
             dist.all_reduce(t)
         return t
 
-    def all_ok(self, ok: bool) -> bool:
-        """A failure on ONE rank must skip the work unit on ALL ranks (or the next collective hangs)."""
-        t = torch.tensor([0.0 if ok else 1.0], device=self.device)
-        return float(self.sum_(t).item()) == 0.0
-
     def barrier(self):
         if self.world > 1:
             import torch.distributed as dist
@@ -191,14 +186,25 @@ def train_rank(args, D, base_model, sets, rank_r, out_dir, mean, std):
             if idx:
                 x, y = train.fetch(idx)
                 x, y = x.to(D.device), y.to(D.device)
-                if args.pgd_inner_steps > 0:
-                    # adversarial batch against the CURRENT adapters (the library commits the last Adam step itself)
-                    engine.set_normalization(mean, std)
-                    x = engine.pgd_attack(x, y, args.epsilon, args.pgd_alpha, args.pgd_inner_steps, random_start=True,
-                                          seed=args.seed + 7919 * epoch + step)
-                logits = peft_model.base_model(pixel_values=x, normalise=True).logits
-                loss = criterion(logits, y)
-                loss.backward()
+                for attempt in (0, 1):
+                    try:
+                        xa = x
+                        if args.pgd_inner_steps > 0:
+                            # adversarial batch against the CURRENT adapters (the library commits the last Adam step itself)
+                            engine.set_normalization(mean, std)
+                            xa = engine.pgd_attack(x, y, args.epsilon, args.pgd_alpha, args.pgd_inner_steps, random_start=True,
+                                                   seed=args.seed + 7919 * epoch + step)
+                        logits = peft_model.base_model(pixel_values=xa, normalise=True).logits
+                        loss = criterion(logits, y)
+                        loss.backward()
+                        break
+                    except V.NonFiniteGradient as e:
+                        # fp16 mode: an EARLIER step's gradient left the fp16 range.  The library reports it at the next call
+                        # (no per-step host sync) and has already done what an AMP skip-step does -- the Adam kernel left every
+                        # non-finite element (parameter and moments) untouched; the flag is cleared by reading it: go on.
+                        if attempt:
+                            raise
+                        print(f"  [rank {D.rank}] an earlier step was (partly) skipped: {e}", flush=True)
                 stats += torch.stack([loss.detach() * len(idx), (logits.detach().argmax(1) == y).sum().float(),
                                       torch.tensor(float(len(idx)), device=D.device)])
             optimizer.step(local_count=len(idx), global_count=n_global)
@@ -319,12 +325,17 @@ def main(argv=None):
                     results = train_lora_for_model_and_attack(model_name, source, attack, args, D)
                 except Exception as e:            # skip-and-continue like the reference (:464-470) ...
                     err = e
-                    print(f"Error training {model_name} on {source} with {attack}: {e}")
-                    print(traceback.format_exc())
-                # ... but only when EVERY rank agrees the unit is over: a rank that failed alone would leave the others
-                # waiting in an all-reduce, so a one-sided failure ends the job instead of desynchronising it
-                if not D.all_ok(err is None) and err is None:
-                    raise RuntimeError("another rank failed in this work unit; stopping to keep the ranks in step")
+                    print(f"Error training {model_name} on {source} with {attack}: {e}", flush=True)
+                    print(traceback.format_exc(), flush=True)
+                    if D.world > 1:
+                        # ... but ONLY in a single process.  With several ranks the others may be anywhere inside the
+                        # unit -- the gradient all-reduce of Adam.step, evaluate()'s sums, the initial broadcast -- and any
+                        # collective entered from here would pair up with one of those (a hang or silently wrong sums under
+                        # RCCL, a size mismatch under gloo).  So no collective from the failure path: this rank exits
+                        # non-zero at once and torch.distributed.run tears the job down.
+                        sys.stdout.flush()
+                        sys.stderr.flush()
+                        os._exit(1)
                 global_results.setdefault(model_name, {}).setdefault(source, {})[attack] = results
     if D.rank == 0:
         os.makedirs(args.output_dir, exist_ok=True)

@@ -131,12 +131,28 @@ def main(argv=None):
             if loaded is None:
                 continue
             model, class_to_idx, mean, std = loaded
-            wrapped = V.LogitsModel(model)
-            engine = atk._unwrap(model)._engine()
-            pgd = None
-            if "pgd" in args.attacks:
-                pgd = V.PGD(wrapped, eps=args.epsilon, alpha=args.pgd_alpha, steps=args.pgd_iters, random_start=True,
-                            seed=args.seed)
+            fallback = {}                    # the same model in fp32, built on first need (a batch whose fp16 backward left its range)
+
+            def attack_batch(mdl, images, labels, batch_seed):
+                """FGSM / PGD on one batch through `mdl` (whitebox_attacks.py:157-173); raises NonFiniteGradient if flagged."""
+                eng = atk._unwrap(mdl)._engine()
+                out = {}
+                if "fgsm" in args.attacks:
+                    out["fgsm"] = V.batched_fgsm_attack(mdl, images, labels, args.epsilon, mean, std)
+                if "pgd" in args.attacks:
+                    if args.canonical_pgd:
+                        # textbook form: attack in [0,1], model fed (x-mean)/std
+                        eng.set_normalization(mean, std)
+                        out["pgd"] = eng.pgd_attack(images, labels, args.epsilon, args.pgd_alpha, args.pgd_iters,
+                                                    random_start=True, seed=batch_seed)
+                    else:
+                        pgd = V.PGD(V.LogitsModel(mdl), eps=args.epsilon, alpha=args.pgd_alpha, steps=args.pgd_iters,
+                                    random_start=True, seed=batch_seed)
+                        pgd.set_normalization_used(mean=mean, std=std)       # whitebox_attacks.py:169
+                        out["pgd"] = pgd(images, labels)
+                eng.check()                  # synchronises; fp16 mode: raises if a gradient left the fp16 range
+                return out, eng
+
             for split in args.splits:
                 print(f"  Processing {split} split...")
                 base_out = os.path.join(args.output_dir, model_name, source_name, split)
@@ -147,18 +163,16 @@ def main(argv=None):
                 for images, labels, filenames in batches(args, split, class_to_idx, model, rank, world):
                     images, labels = images.to(device), labels.to(device)
                     seen.extend(filenames)
-                    out = {}
-                    if "fgsm" in args.attacks:
-                        out["fgsm"] = V.batched_fgsm_attack(model, images, labels, args.epsilon, mean, std)
-                    if pgd is not None:
-                        if args.canonical_pgd:
-                            # textbook form: attack in [0,1], model fed (x-mean)/std
-                            engine.set_normalization(mean, std)
-                            out["pgd"] = engine.pgd_attack(images, labels, args.epsilon, args.pgd_alpha, args.pgd_iters,
-                                                           random_start=True, seed=args.seed + len(seen))
-                        else:
-                            pgd.set_normalization_used(mean=mean, std=std)       # whitebox_attacks.py:169
-                            out["pgd"] = pgd(images, labels)
+                    # random start of PGD: seeded by the batch's first file name, i.e. the same noise whichever rank draws it
+                    batch_seed = args.seed + zlib.crc32(filenames[0].encode()) % (1 << 20)
+                    try:
+                        out, engine = attack_batch(model, images, labels, batch_seed)
+                    except V.NonFiniteGradient as e:
+                        print(f"    fp16 gradient out of range in batch starting at {filenames[0]} ({e}); redoing it in fp32")
+                        if "model" not in fallback:
+                            a32 = argparse.Namespace(**dict(vars(args), precision="f32"))
+                            fallback["model"] = load_model(a32, model_name, source_name, device)[0]
+                        out, engine = attack_batch(fallback["model"], images, labels, batch_seed)
                     for a, adv in out.items():
                         iomod.save_images(adv, filenames, dirs[a], engine=engine)
                 all_seen = seen
@@ -167,7 +181,8 @@ def main(argv=None):
                     # listing, so stale files of an earlier run cannot leak into metadata.csv
                     gathered = [None] * world
                     dist.all_gather_object(gathered, seen)
-                    all_seen = [fn for part in gathered for fn in part]
+                    # dataset order (rank r holds items r, r + world, ...), as the reference's all_filenames (:156-176)
+                    all_seen = [part[i] for i in range(max(len(p) for p in gathered)) for part in gathered if i < len(part)]
                 if not args.synthetic and rank == 0:
                     clean_meta = os.path.join(args.data_root, split, "metadata.csv")
                     for a in args.attacks:
