@@ -1016,6 +1016,11 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_bwd_ring_kernel(const h16
 
     for (int i = tid; i < 3 * ROWS * 8; i += 64 * IMG_WAVES) usum[i] = 0.f;
     for (int i = tid; i < 2 * NT * 2048 / 16; i += 64 * IMG_WAVES) ((f32x4*)sE)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // tile reads past the end of the even-head K image fall into the first rows of the odd-head image, which is not loaded
+    // before head 1: whatever the LDS held there enters dQ's products against ZEROED dS, and 0 x NaN is NaN -- make it zeros
+    // (afterwards the region always holds K rows of some head: finite)
+    if constexpr (ROWS > IR)
+        for (int i = tid; i < (ROWS - IR) * HD * 2 / 16; i += 64 * IMG_WAVES) ((f32x4*)(sK0 + IR * HD))[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // Every wave executes the same barrier sequence: one after the prologue, then per head one per step and one at its end.
     if (w == IMG_WAVES - 1) {

@@ -159,7 +159,9 @@ def test_fp16_backward_out_of_range_is_flagged_never_silent(gain):
         e32.loss_ce(y.cuda())
         g32, _ = e32.backward(True, False, tuple(x.shape))
         e32.check()
-        assert rel_l2(g32.cpu(), g_ref) < 10 * TOL_GRAD["f32"]
+        # (with 512x LayerNorm gains the softmax saturates and the network is ill-conditioned: two fp32 programs agree to a few
+        #  per cent only -- the point here is range, not parity)
+        assert torch.isfinite(g32).all() and rel_l2(g32.cpu(), g_ref) < 0.1
     # the flag is cleared by reading it: the engine is usable again
     eng.check()
 
