@@ -39,6 +39,7 @@ def batched_fgsm_attack(model, images, labels, epsilon, mean, std):
     (whitebox_attacks.py:22-38).  One forward, CE, backward-to-input and one fused step."""
     vit = _unwrap(model)
     eng = vit._engine()
+    vit.sync_params()
     m = [float(v) for v in torch.as_tensor(mean).flatten().tolist()]
     s = [float(v) for v in torch.as_tensor(std).flatten().tolist()]
     eng.set_normalization(m, s)
@@ -68,6 +69,7 @@ class _Attack:
     def _prepare(self, images):
         vit = _unwrap(self.model)
         eng = vit._engine()
+        vit.sync_params()                  # adapters written through torch since the last call: never attack stale operands
         x = images.detach().to(device=eng.device, dtype=torch.float32).contiguous()
         if self._norm is not None:
             mean, std = self._norm

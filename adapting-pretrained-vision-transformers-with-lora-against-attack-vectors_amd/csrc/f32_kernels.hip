@@ -5,6 +5,7 @@
 // clarity, not for the roofline -- the fp16-operand kernels (gemm256.hip, attention32.hip) are the
 // performance path.
 #include <cstdio>
+#include <cstdlib>
 
 #include "f32_kernels.h"
 #include "prof.h"
@@ -93,6 +94,106 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32 p) {
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn * 32 + j * 16 + 4 * (lane >> 4);
             if (n >= p.N) continue;                      // N is a multiple of 4: a lane's 4 columns are in or out together
+            f32x4_t v = acc[i][j] * p.alpha;
+            if (p.bias) v += *(const f32x4_t*)(p.bias + n);
+            if (p.R) v += *(const f32x4_t*)(p.R + (int64_t)m * p.ldr + n);
+            *(f32x4_t*)(p.C + (int64_t)m * p.ldc + n) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same product on 128 x 128 x 16 tiles (round 3): 4 waves (2 x 2), 64 x 64 outputs per wave = 16 accumulators of the
+// 16x16x4 f32 MFMA, i.e. 16 MFMAs per 8 fragment reads (the 64 x 64 kernel above: 4 per 4); the next K tile's global loads
+// are requested before the current tile's products and land in the OTHER LDS buffer after them: one barrier per K tile, the
+// memory latency under 64 MFMAs per wave.  Same arithmetic (k-ordered fmaf chain per output): bit-identical results.
+// Used when the output is at least one tile in both directions; ragged edges are zero-filled / not stored.
+// ---------------------------------------------------------------------------------------------
+constexpr int GBM = 128, GBN = 128;
+
+__global__ __launch_bounds__(256, 2) void gemm_f32_big_kernel(const GemmF32 p) {
+    __shared__ float sA[2][GBM * FLD];
+    __shared__ float sW[2][GBN * FLD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // non-transposed operand: thread -> (row = tid / 2, 8 consecutive k); transposed: (k = tid / 16, 8 consecutive rows)
+    const int r_nt = tid >> 1, k_nt = (tid & 1) * 8;
+    const int k_tr = tid >> 4, r_tr = (tid & 15) * 8;
+    int64_t arow = -1;
+    if (!p.transA) {
+        int m = m0 + r_nt;
+        if (m < p.M) {
+            if (p.a_gather) m = m + m / p.patches + 1;
+            arow = m;
+        }
+    }
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t av[2], wv[2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            av[q] = zero; wv[q] = zero;
+            if (!p.transA) {
+                if (arow >= 0 && k0 + k_nt + 4 * q < p.K) av[q] = *(const f32x4_t*)(p.A + arow * p.lda + k0 + k_nt + 4 * q);
+            } else {
+                if (k0 + k_tr < p.K && m0 + r_tr + 4 * q < p.M) av[q] = *(const f32x4_t*)(p.A + (int64_t)(k0 + k_tr) * p.lda + m0 + r_tr + 4 * q);
+            }
+            if (!p.transW) {
+                if (n0 + r_nt < p.N && k0 + k_nt + 4 * q < p.K) wv[q] = *(const f32x4_t*)(p.W + (int64_t)(n0 + r_nt) * p.ldw + k0 + k_nt + 4 * q);
+            } else {
+                if (k0 + k_tr < p.K && n0 + r_tr + 4 * q < p.N) wv[q] = *(const f32x4_t*)(p.W + (int64_t)(k0 + k_tr) * p.ldw + n0 + r_tr + 4 * q);
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (!p.transA) sA[buf][r_nt * FLD + k_nt + 4 * q + i] = av[q][i];
+                else sA[buf][(r_tr + 4 * q + i) * FLD + k_tr] = av[q][i];
+                if (!p.transW) sW[buf][r_nt * FLD + k_nt + 4 * q + i] = wv[q][i];
+                else sW[buf][(r_tr + 4 * q + i) * FLD + k_tr] = wv[q][i];
+            }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < p.K; k0 += FBK) {
+        const bool more = k0 + FBK < p.K;
+        if (more) fetch(k0 + FBK);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = sA[buf][(wm * 64 + i * 16 + (lane & 15)) * FLD + kk * 4 + (lane >> 4)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[j] = sW[buf][(wn * 64 + j * 16 + (lane & 15)) * FLD + kk * 4 + (lane >> 4)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j], af[i], acc[i][j], 0, 0, 0);   // D[n][m]
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+        if (m >= p.Mstore) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+            if (n >= p.N) continue;
             f32x4_t v = acc[i][j] * p.alpha;
             if (p.bias) v += *(const f32x4_t*)(p.bias + n);
             if (p.R) v += *(const f32x4_t*)(p.R + (int64_t)m * p.ldr + n);
@@ -429,7 +530,10 @@ inline int nblk(int64_t n, int t, int cap) {
 
 }  // namespace
 
+int g_f32_big = 1;       // VITLORA_F32_BIG=0: every fp32 GEMM on the 64 x 64 tile kernel (A/B)
+
 int f32_init(int device) {
+    if (const char* e = getenv("VITLORA_F32_BIG")) g_f32_big = e[0] != '0';
     static bool done[64] = {};
     if (device < 0 || device >= 64) return -1;
     if (done[device]) return 0;
@@ -443,7 +547,14 @@ int f32_init(int device) {
 }
 
 void k_gemm_f32(const GemmF32& g, hipStream_t s) {
-    ProfScope prof_("gemm_f32_kernel", 2.0 * g.M * (double)g.N * g.K, 0.0, s);
+    const double bytes = 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * (g.R ? 2.0 : 1.0));
+    if (g_f32_big && g.M >= GBM && g.N >= GBN) {
+        ProfScope prof_("gemm_f32_big_kernel", 2.0 * g.M * (double)g.N * g.K, bytes, s);
+        dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM);
+        hipLaunchKernelGGL(gemm_f32_big_kernel, grid, dim3(256), 0, s, g);
+        return;
+    }
+    ProfScope prof_("gemm_f32_kernel", 2.0 * g.M * (double)g.N * g.K, bytes, s);
     dim3 grid((g.N + FBN - 1) / FBN, (g.M + FBM - 1) / FBM);
     hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, g);
 }

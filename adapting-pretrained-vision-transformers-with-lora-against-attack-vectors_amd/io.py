@@ -99,3 +99,13 @@ class FolderDataset(torch.utils.data.Dataset):
             m, sd = self.normalise
             x = (x - torch.tensor(m).view(3, 1, 1)) / torch.tensor(sd).view(3, 1, 1)
         return x, self.labels[i], self.filenames[i]
+
+
+def loader_workers(n_items: int) -> int:
+    """DataLoader workers for a dataset of n_items images.  Workers are FORKED from a process that already holds a GPU
+    context (a large address space to copy page tables of, once per loader and epoch): below a few thousand images the
+    forks cost far more than decoding the PNGs in the main process does."""
+    import os
+    if n_items < 4096:
+        return 0
+    return min(4, os.cpu_count() or 1)

@@ -85,7 +85,20 @@ class ViTForImageClassification(torch.nn.Module):
             if self._host_sd:
                 self._eng.load_state_dict(self._host_sd, strict=False)
             self._flat_param = torch.nn.Parameter(self._eng.flat, requires_grad=True)
+            self._seen_version = self._flat_param._version
+            # read-only views of the classifier inside the flat buffer (taken once: asking the library for a pointer marks
+            # the handle dirty, state_dict() must not force a re-pack of the adapters)
+            self._cls_views = (self._eng.param(-1, "", "weight"), self._eng.param(-1, "", "bias"))
         return self._eng
+
+    def sync_params(self):
+        """The facade heals itself: ANY torch-side write to the flat Parameter since the last forward / attack (an in-place
+        optimizer step of the reference's unmodified torch.optim.Adam, copy_, a broadcast, a kept view) bumps its version
+        counter; the library is told so and re-derives the fp16 adapter operands before it runs.  (vl_adam_step and
+        vl_param_* mark the handle themselves.)"""
+        if self._eng is not None and self._flat_param is not None and self._flat_param._version != self._seen_version:
+            self._eng.mark_dirty()
+            self._seen_version = self._flat_param._version
 
     def to(self, device=None, *args, **kwargs):
         if device is not None and not isinstance(device, torch.dtype):
@@ -140,8 +153,8 @@ class ViTForImageClassification(torch.nn.Module):
     def state_dict(self, *args, **kwargs):
         sd = dict(self._host_sd)
         if self._eng is not None:
-            sd["classifier.weight"] = self._eng.param(-1, "", "weight").detach().cpu().clone()
-            sd["classifier.bias"] = self._eng.param(-1, "", "bias").detach().cpu().clone()
+            sd["classifier.weight"] = self._cls_views[0].detach().cpu().clone()
+            sd["classifier.bias"] = self._cls_views[1].detach().cpu().clone()
         return sd
 
     # ---- forward --------------------------------------------------------------------------
@@ -150,6 +163,7 @@ class ViTForImageClassification(torch.nn.Module):
         if x is None:
             raise ValueError("pixel_values is required")
         eng = self._engine()
+        self.sync_params()
         x = x.to(device=eng.device, dtype=torch.float32)
         logits = _ViTFunction.apply(x, self._flat_param, self, bool(normalise))
         return SimpleNamespace(logits=logits)

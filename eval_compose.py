@@ -133,7 +133,7 @@ def main(argv=None):
         def loader(root, meta, sources=None):
             ds = iomod.FolderDataset(root, meta, class_to_idx, image_size=arch.image_size, sources=sources, normalise=(mean, std))
             return lambda: torch.utils.data.DataLoader(ds, batch_size=args.batch_size, shuffle=False,
-                                                       num_workers=min(4, os.cpu_count() or 1))
+                                                       num_workers=iomod.loader_workers(len(ds)))
 
         sets = {"clean": loader(args.data_root, os.path.join(args.data_root, "test", "metadata.csv"), [args.source])}
         adv_base = os.path.join(args.adv_root, args.model_name, args.source, "test")

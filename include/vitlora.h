@@ -89,15 +89,18 @@ int vl_load_tensor(vl_model* m, const char* name, const float* src, int64_t nume
  * Classifier: layer = -1, which 0 = weight [C,D], 1 = bias [C]. */
 int vl_param_tensor(vl_model* m, int layer, uint32_t target, int which, float** ptr, int64_t* numel);
 int vl_param_flat(vl_model* m, float** ptr, int64_t* numel);
-/* Re-derive the bf16 GEMM operands from the flat master buffer (after loading an
+/* Re-derive the 16-bit GEMM operands from the flat master buffer (after loading an
  * adapter, after an optimiser step, or to merge).  PeftModel.from_pretrained /
  * merge_and_unload (train_loras.py:419, eval_compose.py:108-110). */
 int vl_lora_commit(vl_model* m, void* stream);
 /* The library tracks whether the flat parameters changed since the last commit: vl_param_tensor /
  * vl_param_flat hand out writable pointers and mark the handle dirty, vl_adam_step marks the model
  * whose flat buffer it updates, and a caller that writes through a pointer it kept calls
- * vl_params_changed.  vl_forward / vl_pgd_attack commit by themselves when the handle is dirty, so a
- * stale adapter can never be attacked or trained (peft re-reads its Parameters on every forward). */
+ * vl_params_changed.  vl_forward / vl_pgd_attack commit by themselves when the handle is dirty.  The contract is
+ * therefore: writes the library can see (its own entry points) are never stale; a write through a KEPT pointer is the
+ * caller's to announce (vl_params_changed).  The Python facade announces it for every torch-side write by itself (it
+ * compares the flat Parameter's version counter before each forward / attack), so the reference's unmodified
+ * torch.optim.Adam, copy_ and broadcast are covered (peft re-reads its Parameters on every forward). */
 int vl_params_changed(vl_model* m);
 
 /* merge_and_unload for one adapted module (eval_compose.py:102-114): W_out = W_in + (alpha/r) B A,

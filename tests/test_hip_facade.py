@@ -196,6 +196,45 @@ def test_lora_training_steps_match_oracle():
             assert cos > 0.97, (i, t, which, cos)
 
 
+def test_unmodified_torch_optimizer_is_seen_by_the_next_forward():
+    """train_loras.py:284 builds torch.optim.Adam(peft_model.parameters()) -- torch writes the flat Parameter in place, the
+    library never sees that call.  The facade compares the Parameter's version counter before every forward / attack and
+    tells the library, so the fp16 adapter operands are never stale (round-2 ADVICE); same for copy_ and a kept view."""
+    P = pkg()
+    cfg, w, lora, x, y = make_case(batch=4)
+    base = _model(cfg, w)
+    pm = P.setup_peft_lora(base, rank=lora.r, alpha=lora.alpha, dropout=0.0)
+    eng = pm._vit._engine()
+    for (i, t), (A, B) in lora.ab.items():
+        eng.param(i, t, "A").copy_(A)
+        eng.param(i, t, "B").copy_(B)
+    pm.train()
+    crit = torch.nn.CrossEntropyLoss()
+    opt = torch.optim.Adam(pm.parameters(), lr=1e-2)              # the reference's optimizer, unmodified
+    xn = O.normalise(x).cuda()
+    logits0 = pm.base_model(pixel_values=xn).logits
+    loss = crit(logits0, y.cuda())
+    loss.backward()
+    commits = eng.counter("commits")
+    opt.step()                                                     # in-place torch write: bumps the version, nothing else
+    logits1 = pm.base_model(pixel_values=xn).logits
+    assert eng.counter("commits") == commits + 1                   # the forward re-derived the operands
+    assert float((logits1 - logits0).abs().max()) > 1e-4           # ... and they are the new adapters
+    # reference value: the same parameters through a freshly committed engine
+    flat = pm._vit.trainable_flat().detach().clone()
+    eng.commit()
+    logits2 = pm.base_model(pixel_values=xn).logits
+    assert torch.equal(logits1.detach(), logits2.detach())
+    # a write through a kept view + an attack: FGSM must see it too
+    pm.eval()
+    adv0 = P.batched_fgsm_attack(pm, x.cuda(), y.cuda(), 8 / 255, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]).clone()
+    with torch.no_grad():
+        pm._vit.trainable_flat().mul_(0.5)
+    adv1 = P.batched_fgsm_attack(pm, x.cuda(), y.cuda(), 8 / 255, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+    assert float((adv1 != adv0).float().mean()) > 0.01
+    assert torch.isfinite(flat).all()
+
+
 def test_sequential_adapter_merge_matches_summed_update(tmp_path):
     """eval_compose.py:102-114: adapters merged one after the other == W + s*B1*A1 + s*B2*A2 (oracle arithmetic)."""
     P = pkg()

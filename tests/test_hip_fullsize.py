@@ -134,3 +134,79 @@ def test_first_attack_of_a_fresh_process_equals_its_replays():
     lines = [l for l in out.stdout.splitlines() if "captures" in l]
     assert len(lines) == 4 and all("equal to first True" in l for l in lines), out.stdout
     assert all(l.split()[2] == "1" for l in lines), out.stdout          # one capture for four attacks
+
+
+# ---- BASELINE config 4 at full size: Swin-T + LoRA r = 16, batch 256 -------------------------------------------------
+
+def test_swin_t_batch256_pgd_properties_and_shard_invariance():
+    """Swin-T + LoRA r=16 on q,k,v,o,fc2, PGD-2 on 256 images (config 4's batch; PGD-40 is the same step 40 times):
+    eps-ball / pixel range, seeded determinism, and bit-exact shard invariance -- an image's trajectory does not depend on
+    the batch it rides in (the 1/B of the mean loss is a power of two for both batch sizes and vanishes under sign())."""
+    import test_hip_swin as TS
+    m = TS.hf_swin(21, seed=23)
+    ab = TS.add_lora(m, 16, 16.0, seed=25)
+    eng = TS.make_engine(m, 21, 16, ab)
+    g = torch.Generator().manual_seed(27)
+    x = torch.rand(256, 3, 224, 224, generator=g).cuda()
+    y = torch.randint(0, 21, (256,), generator=g).cuda()
+    adv = eng.pgd_attack(x, y, EPS, ALPHA, 2, random_start=True, seed=3).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(adv).all()
+    assert (adv - x).abs().max().item() <= EPS + 1e-6 and adv.min().item() >= 0.0 and adv.max().item() <= 1.0
+    assert ((adv - x).abs() > 1e-7).float().mean().item() > 0.9
+    assert torch.equal(adv, eng.pgd_attack(x, y, EPS, ALPHA, 2, random_start=True, seed=3))
+    # shard invariance needs the same start noise: the library's random start is indexed inside the batch, so start from x
+    full = eng.pgd_attack(x, y, EPS, ALPHA, 2, random_start=False).clone()
+    part = eng.pgd_attack(x[64:128].contiguous(), y[64:128].contiguous(), EPS, ALPHA, 2, random_start=False)
+    assert torch.equal(part, full[64:128]), (part - full[64:128]).abs().max().item()
+
+
+# ---- BASELINE config 5 at full size: ViT-L/16 + LoRA r = 16, adversarial patch EoT step, batch 128 --------------------
+
+def test_vit_l16_batch128_patch_eot_step_properties_and_gradient_exchange():
+    """One EoT step of the 32x32 circular patch on 128 images through the 24-layer ViT-L/16 + LoRA r=16 (config 5's per-GPU
+    batch): the patch stays in the clip range and moves, the step is deterministic for a fixed seed, and the data-parallel
+    identity holds -- the shard-size-weighted sum of the shards' patch gradients equals the full-batch gradient (what the
+    12 KB all-reduce of patch.py computes: patch_attack.py:193-208 under a process group)."""
+    P = pkg()
+    syn = importlib.import_module(PKG + ".synthetic")
+    patch_mod = importlib.import_module(PKG + ".patch")
+    model_mod = importlib.import_module(PKG + ".model")
+    arch = P.ArchConfig(hidden=1024, layers=24, heads=16, mlp=4096, num_labels=21)
+    spec = P.LoraSpec(r=16, alpha=16.0, dropout=0.0, targets=TARGETS)
+    vit = model_mod.ViTForImageClassification(arch, spec, device="cuda:0")
+    vit.load_state_dict(syn.random_state_dict(arch, seed=0))
+    eng = vit._engine()
+    for (i, t), (A, B) in syn.random_lora(arch, 16, TARGETS, seed=1).items():
+        eng.param(i, t, "A").copy_(A)
+        eng.param(i, t, "B").copy_(B)
+    x, y = syn.random_batch(arch, 128, seed=100)
+    x, y = x.cuda(), y.cuda()
+
+    def attack(seed):
+        return patch_mod.AdversarialPatchPyTorch(vit, rotation_max=22.5, scale_min=0.3, scale_max=1.0, learning_rate=5.0, max_iter=1,
+                                                 batch_size=128, patch_shape=(3, 32, 32), patch_type="circle", targeted=False,
+                                                 verbose=False, seed=seed)
+    a1, a2 = attack(3), attack(3)
+    ce1 = float(a1.train_step(x, y))
+    ce2 = float(a2.train_step(x, y))
+    assert ce1 == ce2 and torch.equal(a1._patch, a2._patch)                      # same seed: same transformations, same patch
+    assert 0.0 <= a1._patch.min().item() and a1._patch.max().item() <= 1.0
+    assert (a1._patch - 0.5).abs().max().item() > 0.1                            # Adam lr 5 moved it (then clipped)
+    # patch gradient of the full batch against the weighted sum over four shards, same transformations
+    params = a1.last_params
+    mats = a1._matrices(params)
+    patch = torch.full((3, 32, 32), 0.5, device="cuda:0")
+    eng.set_normalization(a1.mean, a1.std)
+
+    def patch_grad(lo, hi):
+        patched = eng.patch_apply(x[lo:hi].contiguous(), patch, mats[lo:hi].contiguous(), 1)
+        eng.forward(patched, normalise=True, train=False)
+        eng.loss_ce(y[lo:hi].contiguous())
+        gx, _ = eng.backward(True, False, (hi - lo, 3, 224, 224))
+        return eng.patch_grad(gx, mats[lo:hi].contiguous(), 32, 1).clone()
+    g_full = patch_grad(0, 128)
+    g_sum = sum(patch_grad(lo, lo + 32) * (32 / 128.0) for lo in range(0, 128, 32))
+    assert torch.isfinite(g_full).all() and g_full.abs().max().item() > 0
+    rel = float((g_sum.double() - g_full.double()).norm() / g_full.double().norm())
+    assert rel < 1e-5, rel                # per-image gradients are batch-independent; only the fp32 summation order differs

@@ -101,7 +101,7 @@ def batches(args, split, class_to_idx, model, rank, world):
     ds = iomod.FolderDataset(args.data_root, meta, class_to_idx, image_size=arch.image_size, sources=args.sources)
     sub = torch.utils.data.Subset(ds, list(range(rank, len(ds), world)))
     loader = torch.utils.data.DataLoader(sub, batch_size=args.batch_size, shuffle=False,
-                                         num_workers=min(4, os.cpu_count() or 1), pin_memory=True)
+                                         num_workers=iomod.loader_workers(len(sub)), pin_memory=True)
     for images, labels, filenames in loader:
         yield images, labels, list(filenames)
 
