@@ -523,6 +523,237 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(const float* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same attention on the exact-f32 MFMA (round 3; the scalar kernels above stay as the A/B reference, VITLORA_F32_ATTN=0).
+// 16 x 16 tiles of v_mfma_f32_16x16x4_f32, D[m][n] with lane (n = lane & 15, g = lane >> 4) holding rows m = 4g + i.
+// Operand fragments from LDS matrices X[row][ALD]:
+//   frow(X, r0, k0): lane (r, kq) = X[r0 + r][k0 + kq]   -- the MFMA index is the matrix ROW, the k index its column
+//   fcol(X, k0, c0): lane (c, kq) = X[k0 + kq][c0 + c]   -- the MFMA index is the matrix COLUMN, the k index its row
+// A score tile is computed with the summed-next index on the ROWS (S^T[key][q] forward / phase A, S[q][key] phase B): an
+// accumulator then holds, per lane, 4 consecutive k values of ONE column -- it becomes the B operand of the next product
+// after a 4 x 4 exchange between the four lane groups (through a 1 KiB per-wave LDS tile).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float frow(const float* X, int r0, int k0, int lane) { return X[(r0 + (lane & 15)) * ALD + k0 + (lane >> 4)]; }
+__device__ __forceinline__ float fcol(const float* X, int k0, int c0, int lane) { return X[(k0 + (lane >> 4)) * ALD + c0 + (lane & 15)]; }
+__device__ __forceinline__ f32x4_t mfma4(float a, float b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// accumulator tile (lane (n, g), rows 4g + i) -> tile scratch [16 rows][17]
+__device__ __forceinline__ void acc_to_scratch(float* scr, const f32x4_t& v, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) scr[(4 * (lane >> 4) + i) * 17 + (lane & 15)] = v[i];
+}
+// B operand of k-step s4 (rows 4*s4 .. 4*s4+3 of the tile): lane (n, kq) = tile[4*s4 + kq][n]
+__device__ __forceinline__ float scratch_b(const float* scr, int s4, int lane) { return scr[(4 * s4 + (lane >> 4)) * 17 + (lane & 15)]; }
+__device__ __forceinline__ float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+
+// rows [0, T) of a [T][64] operand (row stride ld) -> X[row][ALD]; rows [T, Tp) zero
+__device__ __forceinline__ void attn_stage_pad(float* dst, const float* src, int ld, int T, int Tp, int tid) {
+    for (int i = tid; i < Tp * 16; i += 256) {
+        const int r = i >> 4, c4 = (i & 15) * 4;
+        f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+        if (r < T) v = *(const f32x4_t*)(src + (int64_t)r * ld + c4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[r * ALD + c4 + k] = v[k];
+    }
+}
+size_t attn_mfma_lds_bytes(int T) {
+    const int Tp = (T + 15) / 16 * 16;
+    return ((size_t)2 * Tp * ALD + 2 * Tp + 4 * 2 * 16 * 17) * sizeof(float);
+}
+
+// forward: flash-style over 16-key tiles, one 16-query tile per wave step
+__global__ __launch_bounds__(256) void attn_fwd_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
+                                                                float* __restrict__ lse, int T, int H, int D) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Tp = (T + 15) / 16 * 16, nt = Tp / 16;
+    float* sK = sm;
+    float* sV = sK + Tp * ALD;
+    float* scr = sV + Tp * ALD + 2 * Tp + (threadIdx.x >> 6) * 2 * 16 * 17;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / H, hd = blockIdx.x - b * H;
+    const int ld = 3 * D;
+    const float* base = qkv + (int64_t)b * T * ld + hd * AHD;
+    attn_stage_pad(sK, base + D, ld, T, Tp, tid);
+    attn_stage_pad(sV, base + 2 * D, ld, T, Tp, tid);
+    __syncthreads();
+    for (int qt = w; qt < nt; qt += 4) {
+        const int q = qt * 16 + n, qc = q < T ? q : T - 1;
+        float qf[16];                                  // B operand (n = query, k = feature): lane (n, kq) = Q[q][4s + kq]
+#pragma unroll
+        for (int s = 0; s < 16; ++s) qf[s] = base[(int64_t)qc * ld + 4 * s + g];
+        f32x4_t o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        float m_run = -INFINITY, l_run = 0.f;
+        for (int kt = 0; kt < nt; ++kt) {
+            f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;         // two chains: a dependent f32 MFMA waits 40 cycles, an independent one 32
+#pragma unroll
+            for (int s = 0; s < 16; s += 2) {
+                s0 = mfma4(frow(sK, kt * 16, 4 * s, lane), qf[s], s0);               // S^T[key][q]
+                s1 = mfma4(frow(sK, kt * 16, 4 * s + 4, lane), qf[s + 1], s1);
+            }
+            f32x4_t st = (s0 + s1) * 0.125f;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (kt * 16 + 4 * g + i >= T) st[i] = -INFINITY;
+                mx = fmaxf(mx, st[i]);
+            }
+            mx = group_max(mx);
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = expf(m_run - m_new);            // first tile: exp(-inf) = 0
+            float ps = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { st[i] = expf(st[i] - m_new); ps += st[i]; }
+            l_run = l_run * alpha + group_sum(ps);
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+            acc_to_scratch(scr, st, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float pb = scratch_b(scr, s4, lane);                           // P[key 4*s4 + kq][q]
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt] = mfma4(fcol(sV, kt * 16 + 4 * s4, dt * 16, lane), pb, o[dt]);   // O^T[d][q]
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (q < T) {
+            const float inv = 1.f / l_run;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *(f32x4_t*)(ctx + ((int64_t)b * T + q) * D + hd * AHD + dt * 16 + 4 * g) = o[dt] * inv;
+            if (g == 0) lse[((int64_t)b * H + hd) * T + q] = m_run + logf(l_run);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_f32_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+                                                                const float* __restrict__ dctx, const float* __restrict__ lse,
+                                                                float* __restrict__ dqkv, int T, int H, int D) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Tp = (T + 15) / 16 * 16, nt = Tp / 16;
+    float* sX = sm;
+    float* sY = sX + Tp * ALD;
+    float* sDelta = sY + Tp * ALD;      // [Tp]
+    float* sLse = sDelta + Tp;          // [Tp], rows >= T: +inf (P = 0)
+    float* scr = sLse + Tp + (threadIdx.x >> 6) * 2 * 16 * 17;
+    float* scr2 = scr + 16 * 17;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / H, hd = blockIdx.x - b * H;
+    const int ld = 3 * D;
+    const float* base = qkv + (int64_t)b * T * ld + hd * AHD;
+    const float* dob = dctx + (int64_t)b * T * D + hd * AHD;
+    const float* ob = ctx + (int64_t)b * T * D + hd * AHD;
+    const float* lrow = lse + ((int64_t)b * H + hd) * T;
+    float* dbase = dqkv + (int64_t)b * T * ld + hd * AHD;
+    // ---- phase A: dQ (K, V in LDS; one 16-query tile per wave step) ----
+    attn_stage_pad(sX, base + D, ld, T, Tp, tid);
+    attn_stage_pad(sY, base + 2 * D, ld, T, Tp, tid);
+    for (int i = tid; i < Tp; i += 256) sLse[i] = i < T ? lrow[i] : INFINITY;
+    __syncthreads();
+    for (int qt = w; qt < nt; qt += 4) {
+        const int q = qt * 16 + n, qc = q < T ? q : T - 1;
+        float qf[16], dof[16];
+        float dsum = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            qf[s] = base[(int64_t)qc * ld + 4 * s + g];
+            dof[s] = dob[(int64_t)qc * D + 4 * s + g];
+            dsum = fmaf(dof[s], ob[(int64_t)qc * D + 4 * s + g], dsum);
+        }
+        const float delta = group_sum(dsum);                   // rowsum(dO * O) of query q, the same in its four lanes
+        if (g == 0) sDelta[q] = q < T ? delta : 0.f;
+        const float lq = sLse[q];
+        f32x4_t dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nt; ++kt) {
+            f32x4_t st = {0.f, 0.f, 0.f, 0.f}, dpt = st;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                st = mfma4(frow(sX, kt * 16, 4 * s, lane), qf[s], st);                // S^T[key][q]
+                dpt = mfma4(frow(sY, kt * 16, 4 * s, lane), dof[s], dpt);             // dP^T[key][q]
+            }
+            f32x4_t ds;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float p = expf(st[i] * 0.125f - lq);
+                if (kt * 16 + 4 * g + i >= T) p = 0.f;
+                ds[i] = p * (dpt[i] - delta) * 0.125f;
+            }
+            acc_to_scratch(scr, ds, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float bd = scratch_b(scr, s4, lane);                            // dS[key 4*s4 + kq][q]
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma4(fcol(sX, kt * 16 + 4 * s4, dt * 16, lane), bd, dq[dt]);   // dQ^T[d][q]
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (q < T) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *(f32x4_t*)(dbase + (int64_t)q * ld + dt * 16 + 4 * g) = dq[dt];
+        }
+    }
+    __syncthreads();
+    // ---- phase B: dK, dV (Q, dO in LDS; one 16-key tile per wave step) ----
+    attn_stage_pad(sX, base, ld, T, Tp, tid);
+    attn_stage_pad(sY, dob, D, T, Tp, tid);
+    __syncthreads();
+    for (int kt = w; kt < nt; kt += 4) {
+        const int key = kt * 16 + n, kc = key < T ? key : T - 1;
+        float kf[16], vf[16];                           // B operands (n = key, k = feature)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            kf[s] = base[(int64_t)kc * ld + D + 4 * s + g];
+            vf[s] = base[(int64_t)kc * ld + 2 * D + 4 * s + g];
+        }
+        f32x4_t dk[4], dv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[dt] = dk[dt]; }
+        for (int qt = 0; qt < nt; ++qt) {
+            f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = sc;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                sc = mfma4(frow(sX, qt * 16, 4 * s, lane), kf[s], sc);                // S[q][key]
+                dp = mfma4(frow(sY, qt * 16, 4 * s, lane), vf[s], dp);                // dP[q][key]
+            }
+            f32x4_t p, ds;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int qi = qt * 16 + 4 * g + i;
+                p[i] = expf(sc[i] * 0.125f - sLse[qi]);                               // queries >= T: exp(-inf) = 0
+                ds[i] = p[i] * (dp[i] - sDelta[qi]) * 0.125f;
+            }
+            acc_to_scratch(scr, p, lane);
+            acc_to_scratch(scr2, ds, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float bp = scratch_b(scr, s4, lane), bd = scratch_b(scr2, s4, lane);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dv[dt] = mfma4(fcol(sY, qt * 16 + 4 * s4, dt * 16, lane), bp, dv[dt]);   // dV^T[d][key]
+                    dk[dt] = mfma4(fcol(sX, qt * 16 + 4 * s4, dt * 16, lane), bd, dk[dt]);   // dK^T[d][key]
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (key < T) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                *(f32x4_t*)(dbase + (int64_t)key * ld + D + dt * 16 + 4 * g) = dk[dt];
+                *(f32x4_t*)(dbase + (int64_t)key * ld + 2 * D + dt * 16 + 4 * g) = dv[dt];
+            }
+        }
+    }
+}
+
 inline int nblk(int64_t n, int t, int cap) {
     int64_t b = (n + t - 1) / t;
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -531,6 +762,7 @@ inline int nblk(int64_t n, int t, int cap) {
 }  // namespace
 
 int g_f32_big = 1;       // VITLORA_F32_BIG=0: every fp32 GEMM on the 64 x 64 tile kernel (A/B)
+int g_f32_attn_mfma = 1; // VITLORA_F32_ATTN=0: the scalar fp32 attention kernels (A/B)
 
 int f32_init(int device) {
     if (const char* e = getenv("VITLORA_F32_BIG")) g_f32_big = e[0] != '0';
@@ -542,6 +774,11 @@ int f32_init(int device) {
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)attn_bwd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)attn_fwd_f32_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_mfma_lds_bytes(ATMAX));
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)attn_bwd_f32_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_mfma_lds_bytes(ATMAX));
+    if (e != hipSuccess) return (int)e;
+    if (const char* a = getenv("VITLORA_F32_ATTN")) g_f32_attn_mfma = a[0] != '0';
     done[device] = true;
     return 0;
 }
@@ -589,6 +826,11 @@ void k_patch_scatter_f32(const float* dp, float* gx, int B, int S, int P, const 
 }
 int k_attn_fwd_f32(const float* qkv, float* ctx, float* lse, int B, int T, int H, int D, hipStream_t s) {
     if (T > ATMAX) return -1;
+    if (g_f32_attn_mfma) {
+        ProfScope prof_("attn_fwd_f32_mfma_kernel", 4.0 * B * H * (double)T * T * AHD, (double)B * T * D * 16.0, s);
+        hipLaunchKernelGGL(attn_fwd_f32_mfma_kernel, dim3(B * H), dim3(256), attn_mfma_lds_bytes(T), s, qkv, ctx, lse, T, H, D);
+        return 0;
+    }
     ProfScope prof_("attn_fwd_f32_kernel", 4.0 * B * H * (double)T * T * AHD, 0.0, s);
     hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(B * H), dim3(256), attn_lds_bytes(T), s, qkv, ctx, lse, T, H, D);
     return 0;
@@ -596,6 +838,11 @@ int k_attn_fwd_f32(const float* qkv, float* ctx, float* lse, int B, int T, int H
 int k_attn_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const float* lse, float* dqkv, int B, int T, int H,
                    int D, hipStream_t s) {
     if (T > ATMAX) return -1;
+    if (g_f32_attn_mfma) {
+        ProfScope prof_("attn_bwd_f32_mfma_kernel", 10.0 * B * H * (double)T * T * AHD, (double)B * T * D * 32.0, s);
+        hipLaunchKernelGGL(attn_bwd_f32_mfma_kernel, dim3(B * H), dim3(256), attn_mfma_lds_bytes(T), s, qkv, ctx, dctx, lse, dqkv, T, H, D);
+        return 0;
+    }
     ProfScope prof_("attn_bwd_f32_kernel", 10.0 * B * H * (double)T * T * AHD, 0.0, s);
     hipLaunchKernelGGL(attn_bwd_f32_kernel, dim3(B * H), dim3(256), attn_lds_bytes(T), s, qkv, ctx, dctx, lse, dqkv, T, H, D);
     return 0;
