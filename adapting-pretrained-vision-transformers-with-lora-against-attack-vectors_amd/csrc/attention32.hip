@@ -29,6 +29,13 @@ __device__ unsigned long long g_attn_stamps[8192 * 8 * 8];
 #define STAMP(k) do { } while (0)
 #define ISTAMP(hd, k) do { } while (0)
 #endif
+#ifdef VITLORA_ATTN_STAMPS2   // intra-step stamps of the ring backward (step 3 of head 3), instead of the per-head ones
+#undef ISTAMP
+#define ISTAMP(hd, k) do { } while (0)
+#define JSTAMP(hd, i, k) do { if ((hd) == 3 && (i) == 3) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); if (blockIdx.x < 1024 && (threadIdx.x & 63) == 0) g_attn_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = t_; } } while (0)
+#else
+#define JSTAMP(hd, i, k) do { } while (0)
+#endif
 
 // Workgroup barrier that orders LDS only.  __syncthreads() also drains every wave's GLOBAL loads and stores
 // (s_waitcnt vmcnt(0)) -- in the per-image kernels that made each head wait out its own output stores and the prefetch of
@@ -982,6 +989,9 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_bwd_img_kernel(const h16*
 //   LSE / delta of the head and of the next; u sums; Bd slices.
 //   Loader wave: K of the next head during the steps, Q / dO of the next head under the compute waves' epilogue.
 // ------------------------------------------------------------------------------------------
+#ifndef RING_PRIO
+#define RING_PRIO 0
+#endif
 template <int NT> constexpr int ring_img_rows() { return NT == 7 ? 200 : NT * 32; }
 template <int NT>
 size_t bwd_ring_lds() {
@@ -1167,7 +1177,7 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_bwd_ring_kernel(const h16
     h16x8 fb[4];                            // own v rows (B operand of dP); own k rows are re-read from the K image (registers are short)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) fb[ks] = *(const h16x8*)(base + (size_t)tokc * ld + 2 * D + 8 * h + 16 * ks);
-    if (w >= 4) __builtin_amdgcn_s_setprio(1);
+    if (w >= 4 && RING_PRIO) __builtin_amdgcn_s_setprio(1);
     LDS_BARRIER();
 
 #pragma unroll 1
@@ -1206,6 +1216,7 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_bwd_ring_kernel(const h16
             int qt = w + i; if (qt >= nb) qt -= nb;
             int kt = w - i; if (kt < 0) kt += nb;
             if (i == 3) ISTAMP(hd, 1);
+            JSTAMP(hd, i, 0);
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -1219,15 +1230,24 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_bwd_ring_kernel(const h16
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) { fv0[dt] = tr_frag_o(sdO, qp, 0, fo.tr[dt]); fk0[dt] = tr_frag_o(sQ, qp, 0, fo.tr[dt]); }
             __builtin_amdgcn_sched_barrier(0);
+            JSTAMP(hd, i, 1);
+            char* eslot_w = sE + ((i & 1) * NT + qt) * 2048;
             auto exp_piece = [&](int rq) {
                 const f32x4 lq = *(const f32x4*)(L + qt * 32 + 8 * rq + 4 * h);
                 const f32x4 dl = *(const f32x4*)(Dl + qt * 32 + 8 * rq + 4 * h);
+                h16x4 ds4;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float p = fexp2(fmaf(s[4 * rq + k], scale_log2e, -lq[k]));   // rows >= T: 0
-                    s[4 * rq + k] = p;
-                    dp[4 * rq + k] = p * (dp[4 * rq + k] - dl[k]);
+                    const float d = p * (dp[4 * rq + k] - dl[k]);
+                    // this piece's P and dS leave at once: packed for the own dV / dK products of the NEXT step (the previous
+                    // step's packs of this half were consumed before this piece's arithmetic), and dS to the exchange slot --
+                    // its LDS write completes under the following pieces instead of in front of the barrier
+                    pbk[rq >> 1][4 * (rq & 1) + k] = f2h(p);
+                    ds4[k] = f2h_sat(d);                                               // finite whatever happens (aliasing note above)
+                    dsk[rq >> 1][4 * (rq & 1) + k] = ds4[k];
                 }
+                *(h16x4*)(eslot_w + ewr[rq & 1] + 32 * (rq >> 1)) = ds4;               // queries 8*rq + 4*h + (0..3) of key c
             };
             // piece 0
 #pragma unroll
@@ -1236,6 +1256,7 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_bwd_ring_kernel(const h16
             for (int dt = 0; dt < 2; ++dt) { dv[dt] = mfma32(fv0[dt], pbk[0], dv[dt]); dk[dt] = mfma32(fk0[dt], dsk[0], dk[dt]); }
             exp_piece(0);
             __builtin_amdgcn_sched_barrier(0);
+            JSTAMP(hd, i, 2);
             // piece 1
             d0 = take_ds(i + 1, kp, 0);                                                           // slot set of step i - 1
 #pragma unroll
@@ -1244,6 +1265,7 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_bwd_ring_kernel(const h16
             for (int dt = 0; dt < 2; ++dt) { dv[dt] = mfma32(fv1[dt], pbk[1], dv[dt]); dk[dt] = mfma32(fk1[dt], dsk[1], dk[dt]); }
             exp_piece(1);
             __builtin_amdgcn_sched_barrier(0);
+            JSTAMP(hd, i, 3);
             // piece 2
             d1 = take_ds(i + 1, kp, 1);
 #pragma unroll
@@ -1256,23 +1278,13 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_bwd_ring_kernel(const h16
             for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(fq0[dt], d0, dq[dt]);                   // dQ^T[d][q]
             exp_piece(2);
             __builtin_amdgcn_sched_barrier(0);
+            JSTAMP(hd, i, 4);
             // piece 3
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(fq1[dt], d1, dq[dt]);
             exp_piece(3);
             __builtin_amdgcn_sched_barrier(0);
-            {
-                char* eslot = sE + ((i & 1) * NT + qt) * 2048;
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    h16x4 o4;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) o4[k] = f2h_sat(dp[4 * rq + k]);
-                    *(h16x4*)(eslot + ewr[rq & 1] + 32 * (rq >> 1)) = o4;
-                }
-            }
-#pragma unroll
-            for (int st = 0; st < 2; ++st) { pbk[st] = pack8(s, st); dsk[st] = pack8(dp, st); }
+            JSTAMP(hd, i, 5);
             qp = qt; kp = kt;
             if (i == nb - 1) {
                 // last step: its dV / dK cannot wait -- the loader overwrites the Q / dO images right after this step's barrier
@@ -1285,8 +1297,10 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_bwd_ring_kernel(const h16
                     }
             }
             if (i == 3) ISTAMP(hd, 2);
+            JSTAMP(hd, i, 6);
             LDS_BARRIER();
             if (i == 3) ISTAMP(hd, 3);
+            JSTAMP(hd, i, 7);
         }
         ISTAMP(hd, 4);
         // drain the pipeline: the last step's dQ (K image and exchange slots stay valid until the end-of-head barrier)

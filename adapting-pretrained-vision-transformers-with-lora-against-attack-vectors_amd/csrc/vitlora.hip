@@ -117,7 +117,7 @@ void linear_fwd(vl_model* m, const Linear& ln, const h16* x, h16* t, int Mpad, G
         // long-K projections (fc2: K = 3072, t would cost a pass over the whole GELU output): the ping-pong GEMM computes t
         // itself from the A tiles it streams through LDS anyway (gemm_pp.hip, ND > 0) and still writes it out for wgrad
         bool fused = false;
-        if (!t_ready && xb == x && ln.in >= 2048 && ln.kext == 64) {
+        if (!t_ready && xb == x && ln.in >= m->fuse_down_min_k && ln.kext == 64) {
             GemmArgs f = g;
             f.down_W = ln.Ad; f.down_ldw = ln.in; f.down_out = t; f.down_ld = ln.kext;
             f.down_groups = ext_cols(m, ln) <= 16 ? 1 : ext_cols(m, ln) <= 32 ? 2 : 0;
@@ -249,6 +249,7 @@ int vl_create(const vl_config* cfg, vl_model** out) {
     { const char* re = getenv("VITLORA_RESID"); m->resid_epi = (re && !strcmp(re, "epilogue")) ? 1 : 0; }
     { const char* dr = getenv("VITLORA_DEAD_ROWS"); m->dead_rows = !(dr && dr[0] == '0'); }
     { const char* fp = getenv("VITLORA_FUSE_PGD"); m->fuse_pgd = !(fp && fp[0] == '0'); }
+    { const char* fk = getenv("VITLORA_FUSE_DOWN_MIN_K"); if (fk) m->fuse_down_min_k = atoi(fk); }
     { const char* ai = getenv("VITLORA_ATTN_IMG"); m->attn_img_mode = ai ? (ai[0] == '1' ? 1 : 0) : -1; }
     { hipDeviceProp_t prop; m->num_cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256; }
     const int D = m->D, MLP = m->MLP, r = m->r;
