@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             int M, int D, float eps, const h16* __restrict__ delta,
                                                             float* __restrict__ xout, const h16* __restrict__ P,
-                                                            h16* __restrict__ t) {
+                                                            h16* __restrict__ t, int ldh) {
     const int lane = threadIdx.x & 63;
     const int nv = D >> 2;
     LoraDownP<NV, NG ? NG : 1> pr;                  // fused t = h Ad^T of the projection that reads h next (see layernorm_bwd_kernel)
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             v[i] = c < nv ? *(const f32x4*)(xr + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
             if (delta && c < nv) {
                 // residual add fused in: x_out = x + delta (the h16 output of the projection before it)
-                const h16x4 dl = *(const h16x4*)(delta + (int64_t)row * D + c * 4);
+                const h16x4 dl = *(const h16x4*)(delta + (int64_t)row * ldh + c * 4);   // ldh: row stride of the h16 operands (>= D: padded)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[i][k] += h2f(dl[k]);
                 *(f32x4*)(xout + (int64_t)row * D + c * 4) = v[i];
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         }
         const float rstd = rsqrtf(wave_sum(q) / D + eps);
         if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
-        h16* hr = h + (int64_t)row * D;
+        h16* hr = h + (int64_t)row * ldh;
         h16x4 vb[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const h16* __restric
                                                             const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                             const float* __restrict__ gamma, const float* __restrict__ dres,
                                                             float* __restrict__ dx, h16* __restrict__ dx_h, int M, int D,
-                                                            const h16* __restrict__ P, h16* __restrict__ u, int* __restrict__ err) {
+                                                            const h16* __restrict__ P, h16* __restrict__ u, int* __restrict__ err, int ldh) {
     const int lane = threadIdx.x & 63;
     const int nv = D >> 2;
     bool sat = false;          // a gradient that left the fp16 range (clamped by f2h_sat below) or is NaN: reported, never silent
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const h16* __restric
     if constexpr (NG > 0) lora_down_load<NV, NG>(pr, nv, lane, P, D);
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
     const float mean = mean_in[row], rstd = rstd_in[row];
-    const int64_t off = (int64_t)row * D;
+    const int64_t off = (int64_t)row * D, offh = (int64_t)row * ldh;      // fp32 rows / h16 rows (padded stride)
     f32x4 g[NV], xh[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const h16* __restric
         g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         xh[i] = g[i];
         if (c < nv) {
-            const h16x4 d = *(const h16x4*)(dh + off + c * 4);
+            const h16x4 d = *(const h16x4*)(dh + offh + c * 4);
             const f32x4 xv = *(const f32x4*)(x + off + c * 4);
             const f32x4 gm = *(const f32x4*)(gamma + c * 4);
 #pragma unroll
@@ -228,8 +228,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const h16* __restric
                 ob[k] = f2h_sat(o[k]);
                 sat |= !(fabsf(o[k]) <= 65504.f);
             }
-            *(f32x4*)(dx + off + c * 4) = o;
-            *(h16x4*)(dx_h + off + c * 4) = ob;
+            if (dx) *(f32x4*)(dx + off + c * 4) = o;       // nullptr: nobody reads the fp32 stream below (LN1 of layer 0)
+            *(h16x4*)(dx_h + offh + c * 4) = ob;
             vb[i] = ob;                                              // the row as the next dgrad GEMM reads it
         }
     }
@@ -560,45 +560,47 @@ void k_cls_rows(float* x, const float* cls, const float* pos, int B, int T, int 
 }
 template <int NV>
 static void launch_ln_fwd(dim3 grid, hipStream_t s, const float* x, h16* h, float* mean, float* rstd, const float* g,
-                          const float* b, int M, int D, float eps, const h16* delta, float* xout, const h16* P, int ng, h16* t) {
-    if (ng == 1) hipLaunchKernelGGL((layernorm_fwd_kernel<NV, 1>), grid, dim3(256), 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, t);
-    else if (ng == 2) hipLaunchKernelGGL((layernorm_fwd_kernel<NV, 2>), grid, dim3(256), 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, t);
-    else if (ng == 3) hipLaunchKernelGGL((layernorm_fwd_kernel<NV, 3>), grid, dim3(256), 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, t);
-    else hipLaunchKernelGGL((layernorm_fwd_kernel<NV, 0>), grid, dim3(256), 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, t);
+                          const float* b, int M, int D, float eps, const h16* delta, float* xout, const h16* P, int ng, h16* t, int ldh) {
+    if (ng == 1) hipLaunchKernelGGL((layernorm_fwd_kernel<NV, 1>), grid, dim3(256), 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, t, ldh);
+    else if (ng == 2) hipLaunchKernelGGL((layernorm_fwd_kernel<NV, 2>), grid, dim3(256), 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, t, ldh);
+    else if (ng == 3) hipLaunchKernelGGL((layernorm_fwd_kernel<NV, 3>), grid, dim3(256), 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, t, ldh);
+    else hipLaunchKernelGGL((layernorm_fwd_kernel<NV, 0>), grid, dim3(256), 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, t, ldh);
 }
 void k_layernorm_fwd(const float* x, h16* h, float* mean, float* rstd, const float* g, const float* b, int M, int D,
-                     float eps, const h16* delta, float* xout, const h16* P, int ng, h16* t, hipStream_t s) {
+                     float eps, const h16* delta, float* xout, const h16* P, int ng, h16* t, hipStream_t s, int ldh) {
+    if (ldh <= 0) ldh = D;
     ProfScope prof_("layernorm_fwd_kernel", 0.0, (double)M * D * (delta ? (h ? 12.0 : 10.0) : 6.0), s);
     const int nv = (D / 4 + 63) / 64;
     if (!P || !t || !h || ng < 0 || ng > 3) ng = 0;
     dim3 grid((M + 3) / 4);
     if (ng && grid.x > 1024) grid.x = 1024;          // resident blocks walk the rows, P stays in registers
     switch (nv) {
-        case 1: launch_ln_fwd<1>(grid, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, ng, t); break;
-        case 2: launch_ln_fwd<2>(grid, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, ng, t); break;
-        case 3: launch_ln_fwd<3>(grid, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, ng, t); break;
-        default: launch_ln_fwd<4>(grid, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, ng, t); break;
+        case 1: launch_ln_fwd<1>(grid, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, ng, t, ldh); break;
+        case 2: launch_ln_fwd<2>(grid, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, ng, t, ldh); break;
+        case 3: launch_ln_fwd<3>(grid, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, ng, t, ldh); break;
+        default: launch_ln_fwd<4>(grid, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, ng, t, ldh); break;
     }
 }
 template <int NV>
 static void launch_ln_bwd(dim3 grid, hipStream_t s, const h16* dh, const float* x, const float* mean, const float* rstd,
-                          const float* g, const float* dres, float* dx, h16* dx_h, int M, int D, const h16* P, int ng, h16* u, int* err) {
-    if (ng == 1) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 1>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u, err);
-    else if (ng == 2) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 2>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u, err);
-    else hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 0>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u, err);
+                          const float* g, const float* dres, float* dx, h16* dx_h, int M, int D, const h16* P, int ng, h16* u, int* err, int ldh) {
+    if (ng == 1) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 1>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u, err, ldh);
+    else if (ng == 2) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 2>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u, err, ldh);
+    else hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 0>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u, err, ldh);
 }
 void k_layernorm_bwd(const h16* dh, const float* x, const float* mean, const float* rstd, const float* g,
-                     const float* dres, float* dx, h16* dx_h, int M, int D, const h16* P, int ng, h16* u, hipStream_t s, int* err) {
-    ProfScope prof_("layernorm_bwd_kernel", 0.0, (double)M * D * 16.0, s);
+                     const float* dres, float* dx, h16* dx_h, int M, int D, const h16* P, int ng, h16* u, hipStream_t s, int* err, int ldh) {
+    if (ldh <= 0) ldh = D;
+    ProfScope prof_("layernorm_bwd_kernel", 0.0, (double)M * D * (dx ? 16.0 : 12.0), s);
     const int nv = (D / 4 + 63) / 64;
     if (!P || !u || ng < 0 || ng > 2) ng = 0;
     dim3 grid((M + 3) / 4);
     if (ng && grid.x > 1024) grid.x = 1024;          // 4 resident blocks per CU walk the rows
     switch (nv) {
-        case 1: launch_ln_bwd<1>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, ng, u, err); break;
-        case 2: launch_ln_bwd<2>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, ng, u, err); break;
-        case 3: launch_ln_bwd<3>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, ng, u, err); break;
-        default: launch_ln_bwd<4>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, ng, u, err); break;
+        case 1: launch_ln_bwd<1>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, ng, u, err, ldh); break;
+        case 2: launch_ln_bwd<2>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, ng, u, err, ldh); break;
+        case 3: launch_ln_bwd<3>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, ng, u, err, ldh); break;
+        default: launch_ln_bwd<4>(grid, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, ng, u, err, ldh); break;
     }
 }
 void k_head_fwd(const float* x, int B, int T, int D, int C, float eps, const float* g, const float* b, const float* Wc,

@@ -169,6 +169,7 @@ void set_attr() {
 int g_force_small = -1;
 int g_dephase = -1;
 int g_tile_group = -1;
+int g_skinny_bm = 128;      // VITLORA_SKINNY_BM=64: 64-row tiles (4 LDS stages) for the skinny LoRA-down GEMM
 
 }  // namespace
 
@@ -195,7 +196,8 @@ int gemm_init(int device) {
     g_force_small = (e && e[0] == '1') ? 1 : 0;
     const char* dp = getenv("VITLORA_DEPHASE");      // experiment knob: start-offset unit of gemm256
     if (dp) g_dephase = atoi(dp);
-    if (const char* tg = getenv("VITLORA_TILE_GROUP")) g_tile_group = atoi(tg);     // experiment knob: gemm256 tile walk
+    if (const char* tg = getenv("VITLORA_TILE_GROUP")) g_tile_group = atoi(tg);
+    if (const char* sb = getenv("VITLORA_SKINNY_BM")) g_skinny_bm = atoi(sb);     // experiment knob: gemm256 tile walk
     if (g_attr_err) return g_attr_err;
     done[device] = true;
     return 0;
@@ -223,7 +225,10 @@ void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
     if (bn == 64) {
         switch (epi) {
             // skinny LoRA-down product (HBM-bound on A): 64-row tiles -> 3x more workgroups in flight
-            case EPI_STORE_H16: launch_t<64, EPI_STORE_H16, 128, 2>(a, s); return;
+            case EPI_STORE_H16:
+                if (g_skinny_bm == 64 && a.M % 64 == 0) launch_t<64, EPI_STORE_H16, 64, 4>(a, s);
+                else launch_t<64, EPI_STORE_H16, 128, 2>(a, s);
+                return;
             default: break;
         }
     }

@@ -11,12 +11,13 @@ void k_cls_rows(float* x, const float* cls, const float* pos, int B, int T, int 
 // output of the projection before it), then the LN of x_out; h == nullptr: the add alone.
 // P / ng / t: optional fused LoRA down-projection of the row of h (8*ng rows of P, ng <= 3; t has 64 columns).
 void k_layernorm_fwd(const float* x, h16* h, float* mean, float* rstd, const float* g, const float* b, int M, int D,
-                     float eps, const h16* delta, float* xout, const h16* P, int ng, h16* t, hipStream_t s);
+                     float eps, const h16* delta, float* xout, const h16* P, int ng, h16* t, hipStream_t s,
+                     int ldh = 0);   // ldh: row stride of h / delta (0 = D; > D for zero-padded h16 operands)
 // P / ng / u: optional fused LoRA down-projection of the h16 output row (u[row][0..63] = dx_h[row] . P[j], 8*ng rows
 // of P [>= 8*ng, D]; ng in {1, 2}; u has 64 columns), see lora_down_row in elementwise.hip
 void k_layernorm_bwd(const h16* dh, const float* x, const float* mean, const float* rstd, const float* g,
                      const float* dres, float* dx, h16* dx_h, int M, int D, const h16* P, int ng, h16* u, hipStream_t s,
-                     int* err = nullptr);   // err: mapped host word, set to 2 when a gradient leaves the fp16 range / is NaN
+                     int* err = nullptr, int ldh = 0);   // err: mapped host word, set to 2 when a gradient leaves the fp16 range / is NaN; ldh: row stride of dh / dx_h
 void k_head_fwd(const float* x, int B, int T, int D, int C, float eps, const float* g, const float* b, const float* Wc,
                 const float* bc, float* xhat, float* xf, float* rstd, float* logits, hipStream_t s);
 // err: mapped host word; set to 1 when a label is outside [0, C) (that image's loss / dlogits become NaN)

@@ -246,6 +246,246 @@ __global__ void cls_bwd_kernel(const float* __restrict__ dlogits, const float* _
     dpooled[i] = a;
 }
 
+// ===============================================================================================================
+// 16-bit path (round 3): h16 operands, fp32 accumulation, fp32 residual stream -- the conventions of the ViT fp16 path.
+// Windowed attention on the 16x16x32 h16 MFMA, one wave per (image, window, head): 49 tokens padded to 64 (4 tiles of 16),
+// head_dim 32 = ONE k-step.  D[m][n]: lane (n = lane & 15, g = lane >> 4) holds rows m = 4g + i; an operand fragment is 8
+// k-values per lane.  Score tiles are computed transposed (S^T[key][q]: keys on the rows), so that a lane owns one query:
+// softmax statistics are per lane (+ two shuffles over g), and two stacked tiles (keys 32a + {4g.., 16 + 4g..}) ARE the B
+// operand of the next product once packed to h16.  Operands whose k index is a token are read with the hardware
+// transpose read in the same k order ({4g.., 16 + 4g..}).
+// Per wave in LDS: Q, K, V (dO) row-major [64][32] h16, backward also P and dS as [q][key] images.
+// ===============================================================================================================
+typedef _Float16 sh16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sh16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int W16T = 64;                 // padded tokens of a window
+// row fragment: lane (r, g) = X[r0 + r][8g .. 8g+7]  (k = feature)
+__device__ __forceinline__ sh16x8 wfrag_row(const h16* X, int r0, int lane) {
+    return *(const sh16x8*)(X + (r0 + (lane & 15)) * HDIM + 8 * (lane >> 4));
+}
+// token-k fragment of a row-major [token][LD] image: lane (c, g) = { X[t0 + 4g + j][c0 + c] (j < 4), X[t0 + 16 + 4g + j - 4][c0 + c] }
+template <int LD>
+__device__ __forceinline__ sh16x8 wfrag_tok(const h16* X, int t0, int c0, int lane) {
+    const int g4 = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const h16* a0 = X + (t0 + 4 * g4 + q) * LD + c0 + 4 * p;
+    return cat4(lds_read_tr16(a0), lds_read_tr16(a0 + 16 * LD));
+}
+__device__ __forceinline__ f32x4 wmfma(sh16x8 a, sh16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float wgmax(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float wgsum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+
+// stage the 49 rows of one operand of the window (row stride ld, 32 features from col0) into X[64][32], rows >= 49 zero
+__device__ __forceinline__ void wstage(h16* X, const h16* src, int ld, int col0, int b, int w, int H, int W, int shift, int lane) {
+    // 64 rows x 4 chunks of 16 bytes: lane -> (row = lane, chunk loop)
+    const int p = lane;
+    sh16x8 v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[c][k] = (h16)0.f;
+    if (p < WT) {
+        const h16* r = src + (int64_t)win_row(b, w, p, H, W, shift) * ld + col0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = *(const sh16x8*)(r + 8 * c);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *(sh16x8*)(X + p * HDIM + 8 * c) = v[c];
+}
+
+constexpr int W16_FWD_WAVES = 4;
+__global__ __launch_bounds__(64 * W16_FWD_WAVES) void win16_fwd_kernel(const h16* __restrict__ qkv, int ldq, const float* __restrict__ table,
+                                                                       h16* __restrict__ ctx, int ldc, float* __restrict__ lse, int B, int H,
+                                                                       int W, int C, int heads, int shift) {
+    __shared__ __attribute__((aligned(16))) h16 sm[W16_FWD_WAVES][3][W16T * HDIM];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nW = (H / WS) * (W / WS);
+    const int64_t item = (int64_t)blockIdx.x * W16_FWD_WAVES + wv;
+    if (item >= (int64_t)B * nW * heads) return;
+    const int hd = (int)(item % heads);
+    const int w = (int)((item / heads) % nW);
+    const int b = (int)(item / ((int64_t)heads * nW));
+    h16 *sQ = sm[wv][0], *sK = sm[wv][1], *sV = sm[wv][2];
+    wstage(sQ, qkv, ldq, hd * HDIM, b, w, H, W, shift, lane);
+    wstage(sK, qkv, ldq, C + hd * HDIM, b, w, H, W, shift, lane);
+    wstage(sV, qkv, ldq, 2 * C + hd * HDIM, b, w, H, W, shift, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int n = lane & 15, g = lane >> 4;
+    const float scale = 0.17677669529663687f;
+#pragma unroll 1
+    for (int qt = 0; qt < 4; ++qt) {
+        const int q = qt * 16 + n;                    // this lane's query (window position)
+        const int qp = q < WT ? q : WT - 1;
+        const int reg_q = shift ? win_region(w, qp, H, W, shift) : 0;
+        const sh16x8 qf = wfrag_row(sQ, qt * 16, lane);
+        f32x4 st[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            st[kt] = wmfma(wfrag_row(sK, kt * 16, lane), qf, f32x4{0.f, 0.f, 0.f, 0.f});        // S^T[key][q]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int key = kt * 16 + 4 * g + i;
+                float a = -INFINITY;
+                if (key < WT) {
+                    a = st[kt][i] * scale + table[bias_index(qp, key) * heads + hd];
+                    if (shift && win_region(w, key, H, W, shift) != reg_q) a += -100.0f;
+                }
+                st[kt][i] = a;
+                mx = fmaxf(mx, a);
+            }
+        }
+        mx = wgmax(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { st[kt][i] = expf(st[kt][i] - mx); sum += st[kt][i]; }
+        sum = wgsum(sum);
+        f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            sh16x8 pb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { pb[j] = f2h(st[2 * a][j]); pb[4 + j] = f2h(st[2 * a + 1][j]); }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) o[dt] = wmfma(wfrag_tok<HDIM>(sV, 32 * a, dt * 16, lane), pb, o[dt]);   // O^T[d][q]
+        }
+        if (q < WT) {
+            const float inv = 1.f / sum;
+            const int row = win_row(b, w, q, H, W, shift);
+            h16* dst = ctx + (int64_t)row * ldc + hd * HDIM;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                sh16x4 ov;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ov[i] = f2h(o[dt][i] * inv);
+                *(sh16x4*)(dst + dt * 16 + 4 * g) = ov;
+            }
+            if (g == 0) lse[(int64_t)row * heads + hd] = mx + logf(sum);
+        }
+    }
+}
+
+constexpr int W16_BWD_WAVES = 2;
+constexpr int PLD = 64;                  // row stride of the P / dS images ([q][key] h16)
+__global__ __launch_bounds__(64 * W16_BWD_WAVES) void win16_bwd_kernel(const h16* __restrict__ qkv, int ldq, const float* __restrict__ table,
+                                                                       const h16* __restrict__ dctx, int ldc, const float* __restrict__ lse,
+                                                                       h16* __restrict__ dqkv, int B, int H, int W, int C, int heads,
+                                                                       int shift) {
+    __shared__ __attribute__((aligned(16))) h16 sm[W16_BWD_WAVES][4 * W16T * HDIM + 2 * W16T * PLD];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nW = (H / WS) * (W / WS);
+    const int64_t item = (int64_t)blockIdx.x * W16_BWD_WAVES + wv;
+    if (item >= (int64_t)B * nW * heads) return;
+    const int hd = (int)(item % heads);
+    const int w = (int)((item / heads) % nW);
+    const int b = (int)(item / ((int64_t)heads * nW));
+    h16 *sQ = sm[wv], *sK = sQ + W16T * HDIM, *sV = sK + W16T * HDIM, *sdO = sV + W16T * HDIM;
+    h16 *sP = sdO + W16T * HDIM, *sdS = sP + W16T * PLD;
+    wstage(sQ, qkv, ldq, hd * HDIM, b, w, H, W, shift, lane);
+    wstage(sK, qkv, ldq, C + hd * HDIM, b, w, H, W, shift, lane);
+    wstage(sV, qkv, ldq, 2 * C + hd * HDIM, b, w, H, W, shift, lane);
+    wstage(sdO, dctx, ldc, hd * HDIM, b, w, H, W, shift, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int n = lane & 15, g = lane >> 4;
+    const float scale = 0.17677669529663687f;
+    // ---- per query tile: P^T, dS^T (keys on the rows); dQ from them directly, P / dS also into the [q][key] images ----
+#pragma unroll 1
+    for (int qt = 0; qt < 4; ++qt) {
+        const int q = qt * 16 + n;
+        const int qp = q < WT ? q : WT - 1;
+        const int reg_q = shift ? win_region(w, qp, H, W, shift) : 0;
+        const float lq = q < WT ? lse[(int64_t)win_row(b, w, qp, H, W, shift) * heads + hd] : INFINITY;     // rows >= 49: P = 0
+        const sh16x8 qf = wfrag_row(sQ, qt * 16, lane), dof = wfrag_row(sdO, qt * 16, lane);
+        f32x4 p[4], dp[4];
+        float dsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            p[kt] = wmfma(wfrag_row(sK, kt * 16, lane), qf, f32x4{0.f, 0.f, 0.f, 0.f});          // S^T[key][q]
+            dp[kt] = wmfma(wfrag_row(sV, kt * 16, lane), dof, f32x4{0.f, 0.f, 0.f, 0.f});        // dP^T[key][q]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int key = kt * 16 + 4 * g + i;
+                float pv = 0.f;
+                if (key < WT) {
+                    float a = p[kt][i] * scale + table[bias_index(qp, key) * heads + hd];
+                    if (shift && win_region(w, key, H, W, shift) != reg_q) a += -100.0f;
+                    pv = expf(a - lq);
+                }
+                p[kt][i] = pv;
+                dsum = fmaf(pv, dp[kt][i], dsum);
+            }
+        }
+        const float delta = wgsum(dsum);                 // rowsum(P * dP) = rowsum(dO * O)
+        f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            sh16x4 p4, d4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dp[kt][i] = p[kt][i] * (dp[kt][i] - delta) * scale;        // dS^T
+                p4[i] = f2h(p[kt][i]);
+                d4[i] = f2h_sat(dp[kt][i]);
+            }
+            // images [q][key]: this lane's query row, keys 16kt + 4g .. +3
+            *(sh16x4*)(sP + q * PLD + kt * 16 + 4 * g) = p4;
+            *(sh16x4*)(sdS + q * PLD + kt * 16 + 4 * g) = d4;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            sh16x8 db;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { db[j] = f2h_sat(dp[2 * a][j]); db[4 + j] = f2h_sat(dp[2 * a + 1][j]); }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) dq[dt] = wmfma(wfrag_tok<HDIM>(sK, 32 * a, dt * 16, lane), db, dq[dt]);   // dQ^T[d][q]
+        }
+        if (q < WT) {
+            h16* dst = dqkv + (int64_t)win_row(b, w, q, H, W, shift) * ldq + hd * HDIM;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                sh16x4 ov;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ov[i] = f2h_sat(dq[dt][i]);
+                *(sh16x4*)(dst + dt * 16 + 4 * g) = ov;
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- per key tile: dV^T[d][key] = sum_q dO^T[d][q] P[q][key], dK^T[d][key] = sum_q Q^T[d][q] dS[q][key] ----
+#pragma unroll 1
+    for (int kt = 0; kt < 4; ++kt) {
+        const int key = kt * 16 + n;
+        f32x4 dv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, dk[2] = {dv[0], dv[0]};
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const sh16x8 pb = wfrag_tok<PLD>(sP, 32 * a, kt * 16, lane), db = wfrag_tok<PLD>(sdS, 32 * a, kt * 16, lane);   // k = query, n = key
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dv[dt] = wmfma(wfrag_tok<HDIM>(sdO, 32 * a, dt * 16, lane), pb, dv[dt]);
+                dk[dt] = wmfma(wfrag_tok<HDIM>(sQ, 32 * a, dt * 16, lane), db, dk[dt]);
+            }
+        }
+        if (key < WT) {
+            h16* dst = dqkv + (int64_t)win_row(b, w, key, H, W, shift) * ldq + hd * HDIM;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                sh16x4 kv, vv;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { kv[i] = f2h_sat(dk[dt][i]); vv[i] = f2h_sat(dv[dt][i]); }
+                *(sh16x4*)(dst + C + dt * 16 + 4 * g) = kv;
+                *(sh16x4*)(dst + 2 * C + dt * 16 + 4 * g) = vv;
+            }
+        }
+    }
+}
+
+// out[b][i] = x[b][i] * f[b]  (per-image power-of-two gradient scale of the 16-bit backward and its inverse)
+__global__ void scale_rows_kernel(const float* __restrict__ x, const float* __restrict__ f, float* __restrict__ out, int B, int64_t n) {
+    const int64_t total = (int64_t)B * n, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += stride) out[i] = x[i] * f[i / n];
+}
+
 inline unsigned nblk(int64_t n, int t, int cap) {
     int64_t b = (n + t - 1) / t;
     return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -256,12 +496,18 @@ struct SLin {
     int out = 0, in = 0;
     float *W = nullptr, *b = nullptr;
     std::vector<SLora> slots;
+    // 16-bit path: operands zero-padded to multiples of 128 in both directions (the h16 GEMM kernels' tile sizes)
+    int inP = 0, outP = 0, kext = 0;
+    h16 *W16 = nullptr, *WT16 = nullptr;      // [outP][inP], [inP][outP]
+    float* b16 = nullptr;                     // [outP] fp32, zero padded
+    h16 *Ad = nullptr, *Bu = nullptr, *Bd = nullptr, *Au = nullptr;   // [64][inP], [outP][64] (scaled), [64][outP], [inP][64] (scaled)
 };
 struct SBlock {
     SLin qkv, o, fc1, fc2;
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *table;
     // saved by the forward
     float *xa, *xb, *mean1, *rstd1, *mean2, *rstd2, *qkvbuf, *ctx, *lse, *z;
+    h16 *qkv16 = nullptr, *z16 = nullptr;     // 16-bit path: [Rp][P(3C)], gelu'(z) [Rp][P(4C)]
 };
 struct SStage {
     int C, H, heads, depth;
@@ -269,6 +515,10 @@ struct SStage {
     // downsample (absent after the last stage)
     float *mg_g = nullptr, *mg_b = nullptr, *Wred = nullptr;
     float *mg = nullptr, *mmean = nullptr, *mrstd = nullptr;    // saved
+    // 16-bit path: per-stage scratch (strides are the stage's own padded widths: pad columns stay zero for ever)
+    int CP = 0, C3P = 0, C4P = 0;
+    h16 *h16b = nullptr, *a16 = nullptr, *delta16 = nullptr, *ctx16 = nullptr, *t16 = nullptr, *u16 = nullptr;
+    h16 *dz16 = nullptr, *dqkv16 = nullptr, *dh16 = nullptr, *dctx16 = nullptr, *gh16 = nullptr;
 };
 
 }  // namespace
@@ -289,6 +539,9 @@ struct vl_swin {
     int64_t* stage_labels;
     int* err_flag = nullptr;
     float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    float *gscale = nullptr, *inv_gscale = nullptr, *dlogits_s = nullptr;
+    int f16 = 0;             // cfg.reserved[0] == 1: 16-bit operand path for the blocks (embedding, merging and head stay fp32)
+    int dirty = 1;           // packed h16 operands are stale (weights / adapters written since the last commit)
 };
 
 namespace {
@@ -334,6 +587,109 @@ void lin_dgrad(vl_swin* m, const SLin& ln, const float* dy, int M, float* dx, hi
     }
 }
 
+// ---- 16-bit path: packed operands, block forward / backward --------------------------------------------------------------
+inline int padc(int c) { return (int)round_up(c, 128); }
+
+GemmArgs ga(const h16* A, int lda, const h16* W, int ldw, int K, int M, int N) {
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.A1 = A; g.lda1 = lda; g.W1 = W; g.ldw1 = ldw; g.K1 = K; g.M = M; g.Mvalid = M; g.N = N;
+    return g;
+}
+
+// first LoRA column of a slot inside the 64-wide K extension (q, k, v of the fused projection at 0, r, 2r)
+inline int ext_off_of(const vl_swin* m, const SLin& ln, const SLora& sl) { return ln.slots.size() == 3 ? (sl.row_off / (ln.out / 3)) * m->r : 0; }
+
+// re-derive every h16 operand from the fp32 masters (weights, biases, adapters); idempotent
+void swin16_commit(vl_swin* m, hipStream_t s) {
+    for (SStage& st : m->stages)
+        for (SBlock& bk : st.blocks)
+            for (SLin* ln : {&bk.qkv, &bk.o, &bk.fc1, &bk.fc2}) {
+                k_pack_h16(ln->W, ln->W16, ln->out, ln->in, ln->inP, 0, 1.f, s);
+                k_pack_h16_t(ln->W, ln->WT16, ln->out, ln->in, ln->outP, 0, 1.f, s);
+                (void)hipMemcpyAsync(ln->b16, ln->b, (size_t)ln->out * sizeof(float), hipMemcpyDeviceToDevice, s);
+                for (const SLora& sl : ln->slots) {
+                    const int eo = ext_off_of(m, *ln, sl);
+                    k_pack_h16(sl.A, ln->Ad + (size_t)eo * ln->inP, m->r, ln->in, ln->inP, 0, 1.f, s);
+                    k_pack_h16(sl.B, ln->Bu + (size_t)sl.row_off * 64, sl.out, m->r, 64, eo, m->scaling, s);
+                    k_pack_h16_t(sl.B, ln->Bd + (size_t)eo * ln->outP, sl.out, m->r, ln->outP, sl.row_off, 1.f, s);
+                    k_pack_h16_t(sl.A, ln->Au, m->r, ln->in, 64, eo, m->scaling, s);
+                }
+            }
+    m->dirty = 0;
+}
+
+// y = x W^T + b (+ LoRA as one extra K tile), epilogue `epi`; x [Mp][inP] h16
+void lin16_fwd(vl_swin* m, SStage& st, const SLin& ln, const h16* x, int Mp, int M, GemmArgs g, int epi, hipStream_t s) {
+    g.A1 = x; g.lda1 = ln.inP; g.W1 = ln.W16; g.ldw1 = ln.inP; g.K1 = ln.inP;
+    g.M = Mp; g.Mvalid = M; g.N = ln.outP; g.bias = ln.b16;
+    if (ln.kext) {
+        GemmArgs d = ga(x, ln.inP, ln.Ad, ln.inP, ln.inP, Mp, 64);
+        d.Mvalid = M; d.C = st.t16; d.ldc = 64; d.n_algo = m->r * (int)ln.slots.size();
+        launch_gemm(d, EPI_STORE_H16, 64, s);
+        g.A2 = st.t16; g.lda2 = 64; g.W2 = ln.Bu; g.ldw2 = 64; g.K2 = 64;
+        g.k2_algo = m->r; g.k2_used = m->r * (int)ln.slots.size();
+    }
+    launch_gemm(g, epi, 128, s);
+}
+// dx = dy W (+ LoRA), dy [Mp][outP] h16
+void lin16_dgrad(vl_swin* m, SStage& st, const SLin& ln, const h16* dy, int Mp, int M, GemmArgs g, int epi, hipStream_t s) {
+    g.A1 = dy; g.lda1 = ln.outP; g.W1 = ln.WT16; g.ldw1 = ln.outP; g.K1 = ln.outP;
+    g.M = Mp; g.Mvalid = M; g.N = ln.inP; g.bias = nullptr;
+    if (ln.kext) {
+        GemmArgs d = ga(dy, ln.outP, ln.Bd, ln.outP, ln.outP, Mp, 64);
+        d.Mvalid = M; d.C = st.u16; d.ldc = 64; d.n_algo = m->r;
+        launch_gemm(d, EPI_STORE_H16, 64, s);
+        g.A2 = st.u16; g.lda2 = 64; g.W2 = ln.Au; g.ldw2 = 64; g.K2 = 64;
+        g.k2_algo = m->r * (int)ln.slots.size(); g.k2_used = g.k2_algo;
+    }
+    launch_gemm(g, epi, 128, s);
+}
+
+// One Swin block, forward.  x_in: fp32 residual stream entering LayerNorm 1 (bk.xa); `delta_in`: the h16 output of the
+// previous block's fc2 still to be added to it (nullptr for the first block of a stage).  Leaves the block's own fc2 output
+// in st.delta16 (to be added by whoever consumes the stream next) and the stream before it in bk.xb.
+void swin16_block_fwd(vl_swin* m, SStage& st, SBlock& bk, const float* x_prev, bool add_delta, int B, int shift, hipStream_t s) {
+    const int Cs = st.C, Hs = st.H, M = B * Hs * Hs, Mp = (int)round_up(M, 128);
+    const int nW = (Hs / WS) * (Hs / WS);
+    GemmArgs g;
+    // LayerNorm 1 (+ residual add of the previous block's MLP output: x_prev + delta -> bk.xa)
+    if (add_delta) k_layernorm_fwd(x_prev, st.h16b, bk.mean1, bk.rstd1, bk.ln1_g, bk.ln1_b, M, Cs, m->cfg.ln_eps, st.delta16, bk.xa, nullptr, 0, nullptr, s, st.CP);
+    else k_layernorm_fwd(bk.xa, st.h16b, bk.mean1, bk.rstd1, bk.ln1_g, bk.ln1_b, M, Cs, m->cfg.ln_eps, nullptr, nullptr, nullptr, 0, nullptr, s, st.CP);
+    memset(&g, 0, sizeof g); g.C = bk.qkv16; g.ldc = st.C3P;
+    lin16_fwd(m, st, bk.qkv, st.h16b, Mp, M, g, EPI_STORE_H16, s);
+    hipLaunchKernelGGL(win16_fwd_kernel, dim3(nblk((int64_t)B * nW * st.heads, W16_FWD_WAVES, 1 << 30)), dim3(64 * W16_FWD_WAVES), 0, s,
+                       bk.qkv16, st.C3P, bk.table, st.ctx16, st.CP, bk.lse, B, Hs, Hs, Cs, st.heads, shift);
+    memset(&g, 0, sizeof g); g.C = st.delta16; g.ldc = st.CP;
+    lin16_fwd(m, st, bk.o, st.ctx16, Mp, M, g, EPI_STORE_H16, s);
+    // LayerNorm 2 (+ residual add of the attention output: bk.xa + delta -> bk.xb)
+    k_layernorm_fwd(bk.xa, st.h16b, bk.mean2, bk.rstd2, bk.ln2_g, bk.ln2_b, M, Cs, m->cfg.ln_eps, st.delta16, bk.xb, nullptr, 0, nullptr, s, st.CP);
+    memset(&g, 0, sizeof g); g.C = st.a16; g.ldc = st.C4P; g.C2 = bk.z16; g.ldc2 = st.C4P;
+    lin16_fwd(m, st, bk.fc1, st.h16b, Mp, M, g, EPI_GELU, s);
+    memset(&g, 0, sizeof g); g.C = st.delta16; g.ldc = st.CP;
+    lin16_fwd(m, st, bk.fc2, st.a16, Mp, M, g, EPI_STORE_H16, s);
+}
+
+// One Swin block, backward.  gin (fp32 [M, C]) / st.gh16 (its h16 copy): gradient w.r.t. the block's output stream;
+// writes the gradient w.r.t. its input stream to gout / st.gh16.
+void swin16_block_bwd(vl_swin* m, SStage& st, SBlock& bk, const float* gin, float* gmid, float* gout, int B, int shift, hipStream_t s) {
+    const int Cs = st.C, Hs = st.H, M = B * Hs * Hs, Mp = (int)round_up(M, 128);
+    const int nW = (Hs / WS) * (Hs / WS);
+    GemmArgs g;
+    memset(&g, 0, sizeof g); g.C = st.dz16; g.ldc = st.C4P; g.R = bk.z16; g.ldr = st.C4P;
+    lin16_dgrad(m, st, bk.fc2, st.gh16, Mp, M, g, EPI_GELU_BWD, s);                         // d(z) = (d(out) Wfc2) * gelu'(z)
+    memset(&g, 0, sizeof g); g.C = st.dh16; g.ldc = st.CP;
+    lin16_dgrad(m, st, bk.fc1, st.dz16, Mp, M, g, EPI_STORE_H16, s);
+    k_layernorm_bwd(st.dh16, bk.xb, bk.mean2, bk.rstd2, bk.ln2_g, gin, gmid, st.gh16, M, Cs, nullptr, 0, nullptr, s, m->err_flag, st.CP);
+    memset(&g, 0, sizeof g); g.C = st.dctx16; g.ldc = st.CP;
+    lin16_dgrad(m, st, bk.o, st.gh16, Mp, M, g, EPI_STORE_H16, s);
+    hipLaunchKernelGGL(win16_bwd_kernel, dim3(nblk((int64_t)B * nW * st.heads, W16_BWD_WAVES, 1 << 30)), dim3(64 * W16_BWD_WAVES), 0, s,
+                       bk.qkv16, st.C3P, bk.table, st.dctx16, st.CP, bk.lse, st.dqkv16, B, Hs, Hs, Cs, st.heads, shift);
+    memset(&g, 0, sizeof g); g.C = st.dh16; g.ldc = st.CP;
+    lin16_dgrad(m, st, bk.qkv, st.dqkv16, Mp, M, g, EPI_STORE_H16, s);
+    k_layernorm_bwd(st.dh16, bk.xa, bk.mean1, bk.rstd1, bk.ln1_g, gmid, gout, st.gh16, M, Cs, nullptr, 0, nullptr, s, m->err_flag, st.CP);
+}
+
 int parse2(const char* name, const char* pfx, int* a, const char** rest) {
     const size_t n = strlen(pfx);
     if (strncmp(name, pfx, n) != 0) return 0;
@@ -366,8 +722,12 @@ int vl_swin_create(const vl_swin_config* cfg, vl_swin** out) {
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     if (int e = f32_init(dev)) return vl_fail(VL_ERR_HIP, "f32_init failed (%d)", e);
+    if (cfg->reserved[0] != 0 && cfg->reserved[0] != 1) return vl_fail(VL_ERR_ARG, "precision (reserved[0]) must be 0 (f32) or 1 (f16)");
+    if (cfg->reserved[0] == 1)
+        if (int e = gemm_init(dev)) return vl_fail(VL_ERR_HIP, "gemm_init: hipFuncSetAttribute failed (%d)", e);
     vl_swin* m = new vl_swin();
     m->cfg = *cfg;
+    m->f16 = cfg->reserved[0] == 1;
     m->S = cfg->image_size; m->P = cfg->patch_size; m->G0 = m->S / m->P; m->E = cfg->embed_dim; m->C = cfg->num_labels;
     m->r = cfg->lora_targets ? cfg->lora_r : 0;
     m->scaling = m->r ? cfg->lora_alpha / (float)m->r : 0.f;
@@ -387,7 +747,13 @@ int vl_swin_create(const vl_swin_config* cfg, vl_swin** out) {
         for (SBlock& bk : st.blocks) {
             bk.qkv.out = 3 * Cs; bk.qkv.in = Cs; bk.o.out = Cs; bk.o.in = Cs;
             bk.fc1.out = 4 * Cs; bk.fc1.in = Cs; bk.fc2.out = Cs; bk.fc2.in = 4 * Cs;
-            for (SLin* ln : {&bk.qkv, &bk.o, &bk.fc1, &bk.fc2}) { A_(ln->W, (size_t)ln->out * ln->in); A_(ln->b, ln->out); }
+            for (SLin* ln : {&bk.qkv, &bk.o, &bk.fc1, &bk.fc2}) {
+                A_(ln->W, (size_t)ln->out * ln->in); A_(ln->b, ln->out);
+                if (m->f16) {
+                    ln->inP = padc(ln->in); ln->outP = padc(ln->out);
+                    A_(ln->W16, (size_t)ln->outP * ln->inP); A_(ln->WT16, (size_t)ln->inP * ln->outP); A_(ln->b16, ln->outP);
+                }
+            }
             A_(bk.ln1_g, Cs); A_(bk.ln1_b, Cs); A_(bk.ln2_g, Cs); A_(bk.ln2_b, Cs);
             A_(bk.table, (size_t)(2 * WS - 1) * (2 * WS - 1) * st.heads);
             if (m->r) {
@@ -400,6 +766,13 @@ int vl_swin_create(const vl_swin_config* cfg, vl_swin** out) {
                     lins[ti]->slots.push_back(sl);
                     off += (int64_t)m->r * lins[ti]->in + (int64_t)sl.out * m->r;
                 }
+                if (m->f16)
+                    for (SLin* ln : {&bk.qkv, &bk.o, &bk.fc1, &bk.fc2}) {
+                        if (ln->slots.empty()) continue;
+                        ln->kext = 64;
+                        A_(ln->Ad, (size_t)64 * ln->inP); A_(ln->Bu, (size_t)ln->outP * 64);
+                        A_(ln->Bd, (size_t)64 * ln->outP); A_(ln->Au, (size_t)ln->inP * 64);
+                    }
             }
         }
         if (i < 3) { A_(st.mg_g, 4 * Cs); A_(st.mg_b, 4 * Cs); A_(st.Wred, (size_t)2 * Cs * 4 * Cs); res /= 2; }
@@ -444,6 +817,7 @@ int vl_swin_load_tensor(vl_swin* m, const char* name, const float* src, int64_t 
         HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
         return VL_OK;
     };
+    m->dirty = 1;
     const int PK = 3 * m->P * m->P, Cl = m->E << 3;
     if (!strcmp(name, "swin.embeddings.patch_embeddings.projection.weight")) return copyf(m->Wpe, (int64_t)m->E * PK);
     if (!strcmp(name, "swin.embeddings.patch_embeddings.projection.bias")) return copyf(m->bpe, m->E);
@@ -482,7 +856,7 @@ int vl_swin_load_tensor(vl_swin* m, const char* name, const float* src, int64_t 
 
 int vl_swin_param_flat(vl_swin* m, float** ptr, int64_t* numel) {
     if (!m) return vl_fail(VL_ERR_ARG, "null model");
-    if (ptr) *ptr = m->flat;
+    if (ptr) { *ptr = m->flat; m->dirty = 1; }
     if (numel) *numel = m->flat_n;
     return VL_OK;
 }
@@ -490,6 +864,7 @@ int vl_swin_param_flat(vl_swin* m, float** ptr, int64_t* numel) {
 int vl_swin_param_tensor(vl_swin* m, int stage, int block, uint32_t target, int which, float** ptr, int64_t* numel) {
     if (!m || !ptr || !numel) return vl_fail(VL_ERR_ARG, "null argument");
     if (stage < 0 || stage > 3 || block < 0 || block >= m->stages[stage].depth) return vl_fail(VL_ERR_ARG, "stage / block out of range");
+    m->dirty = 1;            // a writable pointer leaves the library
     SBlock& bk = m->stages[stage].blocks[block];
     SLin* lins[6] = {&bk.qkv, &bk.qkv, &bk.qkv, &bk.o, &bk.fc1, &bk.fc2};
     const int Cs = m->stages[stage].C;
@@ -533,6 +908,16 @@ static size_t swin_carve(vl_swin* m, int B, char* base) {
             bk.qkvbuf = take((size_t)R * 3 * st.C * 4); bk.ctx = take((size_t)R * st.C * 4);
             bk.lse = take((size_t)R * st.heads * 4); bk.z = take((size_t)R * 4 * st.C * 4);
         }
+        if (m->f16) {
+            const int64_t Rp = round_up((int64_t)B * st.H * st.H, 128);
+            st.CP = padc(st.C); st.C3P = padc(3 * st.C); st.C4P = padc(4 * st.C);
+            auto th = [&](size_t n) { return (h16*)take(n * 2); };
+            for (SBlock& bk : st.blocks) { bk.qkv16 = th((size_t)Rp * st.C3P); bk.z16 = th((size_t)Rp * st.C4P); }
+            st.h16b = th((size_t)Rp * st.CP); st.a16 = th((size_t)Rp * st.C4P); st.delta16 = th((size_t)Rp * st.CP);
+            st.ctx16 = th((size_t)Rp * st.CP); st.t16 = th((size_t)Rp * 64); st.u16 = th((size_t)Rp * 64);
+            st.dz16 = th((size_t)Rp * st.C4P); st.dqkv16 = th((size_t)Rp * st.C3P); st.dh16 = th((size_t)Rp * st.CP);
+            st.dctx16 = th((size_t)Rp * st.CP); st.gh16 = th((size_t)Rp * st.CP);
+        }
         if (i < 3) { st.mg = take((size_t)R / 4 * 4 * st.C * 4 + 1024); st.mmean = take((size_t)R); st.mrstd = take((size_t)R); }
         if ((size_t)R * 4 * st.C > big) big = (size_t)R * 4 * st.C;
     }
@@ -543,6 +928,7 @@ static size_t swin_carve(vl_swin* m, int B, char* base) {
     m->pooled = take((size_t)B * Cl * 4); m->dpooled = take((size_t)B * Cl * 4);
     m->logits = take((size_t)B * m->C * 4); m->dlogits = take((size_t)B * m->C * 4);
     m->loss = take(256); m->loss_img = take((size_t)B * 4);
+    m->gscale = take((size_t)B * 4); m->inv_gscale = take((size_t)B * 4); m->dlogits_s = take((size_t)B * m->C * 4);
     m->h = take(big * 4); m->a = take(big * 4); m->dbig = take(big * 4);
     m->dqkv = take(big * 4);
     m->t = take((size_t)R0 * 64 * 4); m->u = take((size_t)R0 * 64 * 4);
@@ -577,6 +963,7 @@ int vl_swin_set_workspace(vl_swin* m, void* ws, size_t bytes) {
 static int swin_forward(vl_swin* m, const float* x, int B, int normalise, hipStream_t s) {
     if (B <= 0 || B > m->max_batch) return vl_fail(VL_ERR_STATE, "batch %d exceeds planned workspace (%d)", B, m->max_batch);
     const int L0 = m->G0 * m->G0, PK = 3 * m->P * m->P;
+    if (m->f16 && m->dirty) swin16_commit(m, s);
     // patch embedding: Conv2d(3, E, k = s = P) as a GEMM over gathered patches, then LayerNorm (SwinEmbeddings)
     k_patch_gather_f32(x, m->patches, B, m->S, m->P, normalise, m->mean, m->stdv, s);
     GemmF32 g = gm(m->patches, PK, m->Wpe, PK, 0, B * L0, m->E, PK, m->emb, m->E);
@@ -587,7 +974,16 @@ static int swin_forward(vl_swin* m, const float* x, int B, int normalise, hipStr
         SStage& st = m->stages[i];
         const int Cs = st.C, Hs = st.H, M = B * Hs * Hs;
         const int nW = (Hs / WS) * (Hs / WS);
-        for (int bi = 0; bi < st.depth; ++bi) {
+        if (m->f16) {
+            // blocks on the 16-bit path; the stream leaves a block as {bk.xb (fp32), st.delta16 (h16)}: the next LayerNorm adds them
+            for (int bi = 0; bi < st.depth; ++bi) {
+                const int shift = (bi & 1) && Hs > WS ? WS / 2 : 0;
+                swin16_block_fwd(m, st, st.blocks[bi], bi ? st.blocks[bi - 1].xb : nullptr, bi > 0, B, shift, s);
+            }
+            k_layernorm_fwd(st.blocks[st.depth - 1].xb, nullptr, nullptr, nullptr, nullptr, nullptr, M, Cs, m->cfg.ln_eps, st.delta16,
+                            i < 3 ? m->dbig : m->xlast, nullptr, 0, nullptr, s, st.CP);      // materialise the stage output (fp32)
+        }
+        for (int bi = 0; bi < (m->f16 ? 0 : st.depth); ++bi) {
             SBlock& bk = st.blocks[bi];
             const int shift = (bi & 1) && Hs > WS ? WS / 2 : 0;          // SwinLayer: no shift when the window covers the map
             float* xout = bi + 1 < st.depth ? st.blocks[bi + 1].xa : (i < 3 ? m->dbig : m->xlast);
@@ -623,7 +1019,15 @@ static int swin_backward(vl_swin* m, float* grad_x, hipStream_t s) {
     const int B = m->cur_B;
     const int Cl = m->E << 3, Ll = m->stages[3].H * m->stages[3].H;
     // head: d(pooled) = dlogits Wc ; d(hfin)[b, t] = d(pooled)[b] / L ; LayerNorm backward
-    hipLaunchKernelGGL(cls_bwd_kernel, dim3(nblk((int64_t)B * Cl, 256, 1 << 30)), dim3(256), 0, s, m->dlogits, m->Wc, m->dpooled, B, m->C, Cl);
+    const float* dlog = m->dlogits;
+    if (m->f16) {
+        // per-image power-of-two scale: the largest |dLoss/dlogits| of an image lands in [2^9, 2^10) (as the ViT 16-bit path;
+        // the chain is linear and per image, so it is exact up to under / overflow and is undone at the pixels)
+        k_grad_scale(m->dlogits, B, m->C, 0, m->gscale, m->inv_gscale, s);
+        hipLaunchKernelGGL(scale_rows_kernel, dim3(nblk((int64_t)B * m->C, 256, 1024)), dim3(256), 0, s, m->dlogits, m->gscale, m->dlogits_s, B, (int64_t)m->C);
+        dlog = m->dlogits_s;
+    }
+    hipLaunchKernelGGL(cls_bwd_kernel, dim3(nblk((int64_t)B * Cl, 256, 1 << 30)), dim3(256), 0, s, dlog, m->Wc, m->dpooled, B, m->C, Cl);
     hipLaunchKernelGGL(mean_pool_bwd_kernel, dim3(nblk((int64_t)B * Ll * Cl, 256, 1 << 30)), dim3(256), 0, s, m->dpooled, m->h, B, Ll, Cl);
     float *gcur = m->g0, *gnext = m->g1;
     k_ln_bwd_f32(m->h, m->xlast, m->fmean, m->frstd, m->fg, nullptr, gcur, B * Ll, Cl, s);
@@ -637,7 +1041,14 @@ static int swin_backward(vl_swin* m, float* grad_x, hipStream_t s) {
             k_ln_bwd_f32(m->dbig, st.mg, st.mmean, st.mrstd, st.mg_g, nullptr, m->h, M / 4, 4 * Cs, s);
             hipLaunchKernelGGL(merge_gather_kernel, dim3(nblk((int64_t)M * Cs, 256, 8192)), dim3(256), 0, s, m->h, gcur, B, Hs, Hs, Cs, 1);
         }
-        for (int bi = st.depth - 1; bi >= 0; --bi) {
+        if (m->f16) {
+            k_pack_h16(gcur, st.gh16, M, Cs, st.CP, 0, 1.f, s);                         // h16 copy of the stage's output gradient
+            for (int bi = st.depth - 1; bi >= 0; --bi) {
+                const int shift = (bi & 1) && Hs > WS ? WS / 2 : 0;
+                swin16_block_bwd(m, st, st.blocks[bi], gcur, gnext, gcur, B, shift, s);
+            }
+        }
+        for (int bi = m->f16 ? -1 : st.depth - 1; bi >= 0; --bi) {
             SBlock& bk = st.blocks[bi];
             const int shift = (bi & 1) && Hs > WS ? WS / 2 : 0;
             lin_dgrad(m, bk.fc2, gcur, M, m->dbig, s);                                   // d(a)
@@ -658,6 +1069,8 @@ static int swin_backward(vl_swin* m, float* grad_x, hipStream_t s) {
         float is[3];
         for (int c = 0; c < 3; ++c) is[c] = m->cur_norm ? 1.f / m->stdv[c] : 1.f;
         k_patch_scatter_f32(m->patches, grad_x, B, m->S, m->P, is, s);
+        if (m->f16)       // undo the per-image gradient scale
+            hipLaunchKernelGGL(scale_rows_kernel, dim3(8192), dim3(256), 0, s, grad_x, m->inv_gscale, grad_x, B, (int64_t)3 * m->S * m->S);
     }
     return VL_OK;
 }

@@ -811,7 +811,8 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
         linear_dgrad(m, ly.lin[LQKV], w.dqkv, w.u, Mpad, g, EPI_STORE_H16, s, l * 4 + LQKV, u_qkv);
         wgrad(ly.lin[LQKV], w.dqkv, w.h1[l], w.t[LQKV][l], w.u, l * 4 + LQKV);
         const int ff = l > 0 ? fused_down(m, m->layers[l - 1].lin[LFC2]) : 0;     // next consumer: fc2 dgrad of the layer below
-        k_layernorm_bwd(w.dh, w.xs[2 * l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, w.dres[cur], w.dres[cur ^ 1], w.dres_h,
+        // (layer 0: the fp32 residual gradient has no reader below -- the patch-embedding dgrad consumes the h16 copy)
+        k_layernorm_bwd(w.dh, w.xs[2 * l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, w.dres[cur], l > 0 ? w.dres[cur ^ 1] : nullptr, w.dres_h,
                         M, D, ff ? m->layers[l - 1].lin[LFC2].Bd : nullptr, ff, w.u, s, m->err_flag);
         cur ^= 1;
     }

@@ -43,7 +43,13 @@ class SwinArch:
 
 
 class SwinEngine:
-    def __init__(self, arch: Optional[SwinArch] = None, lora_r: int = 0, lora_alpha: float = 16.0, lora_targets=(), device="cuda:0"):
+    def __init__(self, arch: Optional[SwinArch] = None, lora_r: int = 0, lora_alpha: float = 16.0, lora_targets=(), device="cuda:0",
+                 precision: str = "f32"):
+        """precision: "f32" (every operand fp32, exact-f32 MFMA) or "f16" (blocks on h16 operands with fp32 accumulation and an
+        fp32 residual stream, windowed attention on the 16x16x32 MFMA; patch embedding, patch merging and the head stay fp32)."""
+        if precision not in ("f32", "f16"):
+            raise ValueError("precision must be 'f32' or 'f16'")
+        self.precision = precision
         if not torch.cuda.is_available():
             raise _lib.VitLoraError("no GPU visible: the Swin path runs on MI355X only (no CPU fallback)")
         self.lib = _lib.load()
@@ -61,6 +67,7 @@ class SwinEngine:
             tb |= VL_T[t]
         cfg.lora_r, cfg.lora_alpha, cfg.lora_targets = (int(lora_r) if tb else 0), float(lora_alpha), tb
         self.lora_r, self.lora_targets = cfg.lora_r, tuple(lora_targets)
+        cfg.reserved = (C.c_int32 * 4)(1 if precision == "f16" else 0, 0, 0, 0)
         h = C.c_void_p()
         check(self.lib.vl_swin_create(C.byref(cfg), C.byref(h)), "vl_swin_create")
         self.h = h
