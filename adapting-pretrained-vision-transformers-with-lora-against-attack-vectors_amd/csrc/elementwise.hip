@@ -240,6 +240,94 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const h16* __restric
 }
 
 // ---------------------------------------------------------------------------------
+// Narrow rows (D <= 128: Swin stage 1 has D = 96): 32 lanes per row, two rows per wave -- with one wave per row 40 of
+// the 64 lanes idle and the kernel runs at half the HBM rate.  Same arithmetic as the kernels above, no LoRA fusion.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ __launch_bounds__(256) void layernorm_fwd_small_kernel(const float* __restrict__ x, h16* __restrict__ h,
+                                                                  float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  int M, int D, float eps, const h16* __restrict__ delta,
+                                                                  float* __restrict__ xout, int ldh) {
+    const int lane = threadIdx.x & 63, li = lane & 31;
+    const int nv = D >> 2;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    const bool live = row < M;
+    const int rr = live ? row : M - 1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (li < nv) {
+        v = *(const f32x4*)(x + (int64_t)rr * D + li * 4);
+        if (delta) {
+            const h16x4 dl = *(const h16x4*)(delta + (int64_t)rr * ldh + li * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += h2f(dl[k]);
+            if (live) *(f32x4*)(xout + (int64_t)rr * D + li * 4) = v;
+        }
+    }
+    if (!h) return;
+    const float mean = half_wave_sum(v[0] + v[1] + v[2] + v[3]) / D;
+    float q = 0.f;
+    if (li < nv) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float d = v[k] - mean; q += d * d; }
+    }
+    const float rstd = rsqrtf(half_wave_sum(q) / D + eps);
+    if (!live) return;
+    if (li == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    if (li < nv) {
+        const f32x4 g = *(const f32x4*)(gamma + li * 4), b = *(const f32x4*)(beta + li * 4);
+        h16x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = f2h((v[k] - mean) * rstd * g[k] + b[k]);
+        *(h16x4*)(h + (int64_t)row * ldh + li * 4) = o;
+    }
+}
+__global__ __launch_bounds__(256) void layernorm_bwd_small_kernel(const h16* __restrict__ dh, const float* __restrict__ x,
+                                                                  const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                                  float* __restrict__ dx, h16* __restrict__ dx_h, int M, int D,
+                                                                  int* __restrict__ err, int ldh) {
+    const int lane = threadIdx.x & 63, li = lane & 31;
+    const int nv = D >> 2;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    const bool live = row < M;
+    const int rr = live ? row : M - 1;
+    const float mean = mean_in[rr], rstd = rstd_in[rr];
+    f32x4 g = {0.f, 0.f, 0.f, 0.f}, xh = g;
+    float s1 = 0.f, s2 = 0.f;
+    if (li < nv) {
+        const h16x4 d = *(const h16x4*)(dh + (int64_t)rr * ldh + li * 4);
+        const f32x4 xv = *(const f32x4*)(x + (int64_t)rr * D + li * 4);
+        const f32x4 gm = *(const f32x4*)(gamma + li * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            g[k] = h2f(d[k]) * gm[k];
+            xh[k] = (xv[k] - mean) * rstd;
+            s1 += g[k];
+            s2 += g[k] * xh[k];
+        }
+    }
+    const float c1 = half_wave_sum(s1) / D, c2 = half_wave_sum(s2) / D;
+    if (!live || li >= nv) return;
+    const f32x4 r = *(const f32x4*)(dres + (int64_t)row * D + li * 4);
+    f32x4 o; h16x4 ob;
+    bool sat = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        o[k] = r[k] + rstd * (g[k] - c1 - xh[k] * c2);
+        ob[k] = f2h_sat(o[k]);
+        sat |= !(fabsf(o[k]) <= 65504.f);
+    }
+    if (dx) *(f32x4*)(dx + (int64_t)row * D + li * 4) = o;
+    *(h16x4*)(dx_h + (int64_t)row * ldh + li * 4) = ob;
+    if (sat && err) *err = 2;
+}
+
+// ---------------------------------------------------------------------------------
 // CLS head: final LayerNorm on token 0 + classifier (fp32) -- modeling_vit.py:385,560-561.
 // one block (256 threads) per image.
 // ---------------------------------------------------------------------------------
@@ -569,6 +657,11 @@ static void launch_ln_fwd(dim3 grid, hipStream_t s, const float* x, h16* h, floa
 void k_layernorm_fwd(const float* x, h16* h, float* mean, float* rstd, const float* g, const float* b, int M, int D,
                      float eps, const h16* delta, float* xout, const h16* P, int ng, h16* t, hipStream_t s, int ldh) {
     if (ldh <= 0) ldh = D;
+    if (D <= 128 && !(P && t && ng > 0)) {          // narrow rows: two per wave
+        ProfScope prof_("layernorm_fwd_kernel", 0.0, (double)M * D * (delta ? (h ? 12.0 : 10.0) : 6.0), s);
+        hipLaunchKernelGGL(layernorm_fwd_small_kernel, dim3((M + 7) / 8), dim3(256), 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, ldh);
+        return;
+    }
     ProfScope prof_("layernorm_fwd_kernel", 0.0, (double)M * D * (delta ? (h ? 12.0 : 10.0) : 6.0), s);
     const int nv = (D / 4 + 63) / 64;
     if (!P || !t || !h || ng < 0 || ng > 3) ng = 0;
@@ -591,6 +684,11 @@ static void launch_ln_bwd(dim3 grid, hipStream_t s, const h16* dh, const float* 
 void k_layernorm_bwd(const h16* dh, const float* x, const float* mean, const float* rstd, const float* g,
                      const float* dres, float* dx, h16* dx_h, int M, int D, const h16* P, int ng, h16* u, hipStream_t s, int* err, int ldh) {
     if (ldh <= 0) ldh = D;
+    if (D <= 128 && !(P && u && ng > 0)) {
+        ProfScope prof_("layernorm_bwd_kernel", 0.0, (double)M * D * (dx ? 16.0 : 12.0), s);
+        hipLaunchKernelGGL(layernorm_bwd_small_kernel, dim3((M + 7) / 8), dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, err, ldh);
+        return;
+    }
     ProfScope prof_("layernorm_bwd_kernel", 0.0, (double)M * D * (dx ? 16.0 : 12.0), s);
     const int nv = (D / 4 + 63) / 64;
     if (!P || !u || ng < 0 || ng > 2) ng = 0;

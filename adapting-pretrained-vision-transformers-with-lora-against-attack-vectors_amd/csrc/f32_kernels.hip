@@ -248,22 +248,34 @@ __global__ __launch_bounds__(256) void ln_fwd_f32_kernel(const float* __restrict
     }
 }
 
+template <int G>
+__device__ __forceinline__ float lane_group_sum(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dh * gamma
+// NV float4 chunks per lane, G lanes per row (64 / G rows per wave): narrow rows (Swin stage 1: D = 96) would otherwise leave
+// 40 of 64 lanes idle and carry the registers of the widest row the kernel supports
+template <int NV, int G>
 __global__ __launch_bounds__(256) void ln_bwd_f32_kernel(const float* __restrict__ dh, const float* __restrict__ x,
                                                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                          const float* __restrict__ gamma, const float* __restrict__ dres,
                                                          float* __restrict__ dx, int M, int D) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const float mean = mean_in[row], rstd = rstd_in[row];
-    const int64_t off = (int64_t)row * D;
+    constexpr int RPW = 64 / G;
+    const int lane = threadIdx.x & 63, li = lane & (G - 1);
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / G;
+    const bool live = row < M;
+    const int rr = live ? row : M - 1;
+    const float mean = mean_in[rr], rstd = rstd_in[rr];
+    const int64_t off = (int64_t)rr * D;
     const int nv = D >> 2;
-    f32x4_t g[LNV], xh[LNV];
+    f32x4_t g[NV], xh[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LNV; ++i) {
-        const int c = lane + i * 64;
+    for (int i = 0; i < NV; ++i) {
+        const int c = li + i * G;
         g[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         xh[i] = g[i];
         if (c < nv) {
@@ -279,10 +291,11 @@ __global__ __launch_bounds__(256) void ln_bwd_f32_kernel(const float* __restrict
             }
         }
     }
-    const float c1 = wave_sum(s1) / D, c2 = wave_sum(s2) / D;
+    const float c1 = lane_group_sum<G>(s1) / D, c2 = lane_group_sum<G>(s2) / D;
+    if (!live) return;
 #pragma unroll
-    for (int i = 0; i < LNV; ++i) {
-        const int c = lane + i * 64;
+    for (int i = 0; i < NV; ++i) {
+        const int c = li + i * G;
         if (c < nv) {
             const f32x4_t r = dres ? *(const f32x4_t*)(dres + off + c * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
             f32x4_t o;
@@ -801,7 +814,11 @@ void k_ln_fwd_f32(const float* x, float* h, float* mean, float* rstd, const floa
 }
 void k_ln_bwd_f32(const float* dh, const float* x, const float* mean, const float* rstd, const float* g, const float* dres,
                   float* dx, int M, int D, hipStream_t s) {
-    hipLaunchKernelGGL(ln_bwd_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, M, D);
+    const int nv = D / 4;
+#define LNB(NV_, G_) hipLaunchKernelGGL((ln_bwd_f32_kernel<NV_, G_>), dim3((M + 4 * (64 / G_) - 1) / (4 * (64 / G_))), dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, M, D)
+    if (nv <= 16) LNB(1, 16); else if (nv <= 32) LNB(1, 32); else if (nv <= 64) LNB(1, 64); else if (nv <= 128) LNB(2, 64);
+    else if (nv <= 256) LNB(4, 64); else LNB(8, 64);
+#undef LNB
 }
 void k_gelu_fwd_f32(const float* z, float* a, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(gelu_fwd_f32_kernel, dim3(nblk(n, 256, 8192)), dim3(256), 0, s, z, a, n);

@@ -260,16 +260,26 @@ typedef _Float16 sh16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 sh16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int W16T = 64;                 // padded tokens of a window
+// LDS layouts (bank-conflict free for every access kind below):
+//   operand tiles [64 tokens][32 features] h16, 64-byte rows: 16-byte chunk c of row r stored at chunk c ^ ((r >> 2) & 3)
+//   P / dS images [64 queries][64 keys] h16, 128-byte rows:   8-byte chunk c of row r stored at chunk c ^ (r & 15)
+__device__ __forceinline__ int wtile_off(int r, int col) { return r * HDIM + ((((col >> 3) ^ ((r >> 2) & 3)) << 3) | (col & 7)); }
+__device__ __forceinline__ int wimg_off(int r, int col) { return r * 64 + ((((col >> 2) ^ (r & 15)) << 2) | (col & 3)); }
 // row fragment: lane (r, g) = X[r0 + r][8g .. 8g+7]  (k = feature)
 __device__ __forceinline__ sh16x8 wfrag_row(const h16* X, int r0, int lane) {
-    return *(const sh16x8*)(X + (r0 + (lane & 15)) * HDIM + 8 * (lane >> 4));
+    return *(const sh16x8*)(X + wtile_off(r0 + (lane & 15), 8 * (lane >> 4)));
 }
-// token-k fragment of a row-major [token][LD] image: lane (c, g) = { X[t0 + 4g + j][c0 + c] (j < 4), X[t0 + 16 + 4g + j - 4][c0 + c] }
-template <int LD>
-__device__ __forceinline__ sh16x8 wfrag_tok(const h16* X, int t0, int c0, int lane) {
+// token-k fragment of an operand tile: lane (c, g) = { X[t0 + 4g + j][c0 + c] (j < 4), X[t0 + 16 + 4g + j - 4][c0 + c] }
+__device__ __forceinline__ sh16x8 wfrag_tok_tile(const h16* X, int t0, int c0, int lane) {
     const int g4 = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-    const h16* a0 = X + (t0 + 4 * g4 + q) * LD + c0 + 4 * p;
-    return cat4(lds_read_tr16(a0), lds_read_tr16(a0 + 16 * LD));
+    const int r = t0 + 4 * g4 + q;
+    return cat4(lds_read_tr16(X + wtile_off(r, c0 + 4 * p)), lds_read_tr16(X + wtile_off(r + 16, c0 + 4 * p)));
+}
+// the same of a P / dS image
+__device__ __forceinline__ sh16x8 wfrag_tok_img(const h16* X, int t0, int c0, int lane) {
+    const int g4 = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int r = t0 + 4 * g4 + q;
+    return cat4(lds_read_tr16(X + wimg_off(r, c0 + 4 * p)), lds_read_tr16(X + wimg_off(r + 16, c0 + 4 * p)));
 }
 __device__ __forceinline__ f32x4 wmfma(sh16x8 a, sh16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float wgmax(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
@@ -290,7 +300,7 @@ __device__ __forceinline__ void wstage(h16* X, const h16* src, int ld, int col0,
         for (int c = 0; c < 4; ++c) v[c] = *(const sh16x8*)(r + 8 * c);
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) *(sh16x8*)(X + p * HDIM + 8 * c) = v[c];
+    for (int c = 0; c < 4; ++c) *(sh16x8*)(X + wtile_off(p, 8 * c)) = v[c];
 }
 
 constexpr int W16_FWD_WAVES = 4;
@@ -349,7 +359,7 @@ __global__ __launch_bounds__(64 * W16_FWD_WAVES) void win16_fwd_kernel(const h16
 #pragma unroll
             for (int j = 0; j < 4; ++j) { pb[j] = f2h(st[2 * a][j]); pb[4 + j] = f2h(st[2 * a + 1][j]); }
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) o[dt] = wmfma(wfrag_tok<HDIM>(sV, 32 * a, dt * 16, lane), pb, o[dt]);   // O^T[d][q]
+            for (int dt = 0; dt < 2; ++dt) o[dt] = wmfma(wfrag_tok_tile(sV, 32 * a, dt * 16, lane), pb, o[dt]);   // O^T[d][q]
         }
         if (q < WT) {
             const float inv = 1.f / sum;
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(64 * W16_FWD_WAVES) void win16_fwd_kernel(const h16
     }
 }
 
-constexpr int W16_BWD_WAVES = 2;
+constexpr int W16_BWD_WAVES = 1;          // 32 KiB of LDS per wave: one wave per workgroup lets five of them share a CU
 constexpr int PLD = 64;                  // row stride of the P / dS images ([q][key] h16)
 __global__ __launch_bounds__(64 * W16_BWD_WAVES) void win16_bwd_kernel(const h16* __restrict__ qkv, int ldq, const float* __restrict__ table,
                                                                        const h16* __restrict__ dctx, int ldc, const float* __restrict__ lse,
@@ -429,8 +439,8 @@ __global__ __launch_bounds__(64 * W16_BWD_WAVES) void win16_bwd_kernel(const h16
                 d4[i] = f2h_sat(dp[kt][i]);
             }
             // images [q][key]: this lane's query row, keys 16kt + 4g .. +3
-            *(sh16x4*)(sP + q * PLD + kt * 16 + 4 * g) = p4;
-            *(sh16x4*)(sdS + q * PLD + kt * 16 + 4 * g) = d4;
+            *(sh16x4*)(sP + wimg_off(q, kt * 16 + 4 * g)) = p4;
+            *(sh16x4*)(sdS + wimg_off(q, kt * 16 + 4 * g)) = d4;
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -438,7 +448,7 @@ __global__ __launch_bounds__(64 * W16_BWD_WAVES) void win16_bwd_kernel(const h16
 #pragma unroll
             for (int j = 0; j < 4; ++j) { db[j] = f2h_sat(dp[2 * a][j]); db[4 + j] = f2h_sat(dp[2 * a + 1][j]); }
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) dq[dt] = wmfma(wfrag_tok<HDIM>(sK, 32 * a, dt * 16, lane), db, dq[dt]);   // dQ^T[d][q]
+            for (int dt = 0; dt < 2; ++dt) dq[dt] = wmfma(wfrag_tok_tile(sK, 32 * a, dt * 16, lane), db, dq[dt]);   // dQ^T[d][q]
         }
         if (q < WT) {
             h16* dst = dqkv + (int64_t)win_row(b, w, q, H, W, shift) * ldq + hd * HDIM;
@@ -459,11 +469,11 @@ __global__ __launch_bounds__(64 * W16_BWD_WAVES) void win16_bwd_kernel(const h16
         f32x4 dv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, dk[2] = {dv[0], dv[0]};
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            const sh16x8 pb = wfrag_tok<PLD>(sP, 32 * a, kt * 16, lane), db = wfrag_tok<PLD>(sdS, 32 * a, kt * 16, lane);   // k = query, n = key
+            const sh16x8 pb = wfrag_tok_img(sP, 32 * a, kt * 16, lane), db = wfrag_tok_img(sdS, 32 * a, kt * 16, lane);   // k = query, n = key
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                dv[dt] = wmfma(wfrag_tok<HDIM>(sdO, 32 * a, dt * 16, lane), pb, dv[dt]);
-                dk[dt] = wmfma(wfrag_tok<HDIM>(sQ, 32 * a, dt * 16, lane), db, dk[dt]);
+                dv[dt] = wmfma(wfrag_tok_tile(sdO, 32 * a, dt * 16, lane), pb, dv[dt]);
+                dk[dt] = wmfma(wfrag_tok_tile(sQ, 32 * a, dt * 16, lane), db, dk[dt]);
             }
         }
         if (key < WT) {
@@ -519,6 +529,7 @@ struct SStage {
     int CP = 0, C3P = 0, C4P = 0;
     h16 *h16b = nullptr, *a16 = nullptr, *delta16 = nullptr, *ctx16 = nullptr, *t16 = nullptr, *u16 = nullptr;
     h16 *dz16 = nullptr, *dqkv16 = nullptr, *dh16 = nullptr, *dctx16 = nullptr, *gh16 = nullptr;
+    h16 *Wred16 = nullptr, *WredT16 = nullptr, *mg16 = nullptr, *g16 = nullptr;     // patch-merging reduction on h16 operands
 };
 
 }  // namespace
@@ -616,6 +627,11 @@ void swin16_commit(vl_swin* m, hipStream_t s) {
                     k_pack_h16_t(sl.A, ln->Au, m->r, ln->in, 64, eo, m->scaling, s);
                 }
             }
+    for (int i = 0; i < 3; ++i) {
+        SStage& st = m->stages[i];
+        k_pack_h16(st.Wred, st.Wred16, 2 * st.C, 4 * st.C, 4 * st.C, 0, 1.f, s);
+        k_pack_h16_t(st.Wred, st.WredT16, 2 * st.C, 4 * st.C, 2 * st.C, 0, 1.f, s);
+    }
     m->dirty = 0;
 }
 
@@ -775,7 +791,10 @@ int vl_swin_create(const vl_swin_config* cfg, vl_swin** out) {
                     }
             }
         }
-        if (i < 3) { A_(st.mg_g, 4 * Cs); A_(st.mg_b, 4 * Cs); A_(st.Wred, (size_t)2 * Cs * 4 * Cs); res /= 2; }
+        if (i < 3) {
+            A_(st.mg_g, 4 * Cs); A_(st.mg_b, 4 * Cs); A_(st.Wred, (size_t)2 * Cs * 4 * Cs); res /= 2;
+            if (m->f16) { A_(st.Wred16, (size_t)2 * Cs * 4 * Cs); A_(st.WredT16, (size_t)4 * Cs * 2 * Cs); }
+        }
     }
     const int Cl = m->E << 3;
     A_(m->fg, Cl); A_(m->fb, Cl); A_(m->Wc, (size_t)m->C * Cl); A_(m->bc, m->C);
@@ -901,7 +920,7 @@ static size_t swin_carve(vl_swin* m, int B, char* base) {
     size_t big = 0;
     for (int i = 0; i < 4; ++i) {
         SStage& st = m->stages[i];
-        const int64_t R = round_up((int64_t)B * st.H * st.H, 64);
+        const int64_t R = round_up((int64_t)B * st.H * st.H, 512);     // (a quarter of it is still a multiple of the GEMM row tile)
         for (SBlock& bk : st.blocks) {
             bk.xa = take((size_t)R * st.C * 4); bk.xb = take((size_t)R * st.C * 4);
             bk.mean1 = take((size_t)R * 4); bk.rstd1 = take((size_t)R * 4); bk.mean2 = take((size_t)R * 4); bk.rstd2 = take((size_t)R * 4);
@@ -917,6 +936,7 @@ static size_t swin_carve(vl_swin* m, int B, char* base) {
             st.ctx16 = th((size_t)Rp * st.CP); st.t16 = th((size_t)Rp * 64); st.u16 = th((size_t)Rp * 64);
             st.dz16 = th((size_t)Rp * st.C4P); st.dqkv16 = th((size_t)Rp * st.C3P); st.dh16 = th((size_t)Rp * st.CP);
             st.dctx16 = th((size_t)Rp * st.CP); st.gh16 = th((size_t)Rp * st.CP);
+            if (i < 3) { const int64_t Rq = round_up(Rp / 4, 128); st.mg16 = th((size_t)Rq * 4 * st.C); st.g16 = th((size_t)Rq * 2 * st.C); }
         }
         if (i < 3) { st.mg = take((size_t)R / 4 * 4 * st.C * 4 + 1024); st.mmean = take((size_t)R); st.mrstd = take((size_t)R); }
         if ((size_t)R * 4 * st.C > big) big = (size_t)R * 4 * st.C;
@@ -1001,6 +1021,13 @@ static int swin_forward(vl_swin* m, const float* x, int B, int normalise, hipStr
             hipLaunchKernelGGL(merge_gather_kernel, dim3(nblk((int64_t)M * Cs, 256, 8192)), dim3(256), 0, s, m->dbig, st.mg, B, Hs,
                                Hs, Cs, 0);
             k_ln_fwd_f32(st.mg, m->h, st.mmean, st.mrstd, st.mg_g, st.mg_b, M / 4, 4 * Cs, m->cfg.ln_eps, s);
+            if (m->f16 && (2 * Cs) % 128 == 0) {      // reduction on h16 operands (the 2C = 192 one keeps fp32: its width is not a GEMM tile multiple)
+                const int Mq = (int)round_up(M / 4, 128);
+                k_pack_h16(m->h, st.mg16, M / 4, 4 * Cs, 4 * Cs, 0, 1.f, s);
+                GemmArgs g16a = ga(st.mg16, 4 * Cs, st.Wred16, 4 * Cs, 4 * Cs, Mq, 2 * Cs);
+                g16a.Mvalid = M / 4; g16a.C = m->stages[i + 1].blocks[0].xa; g16a.ldc = 2 * Cs;
+                launch_gemm(g16a, EPI_STORE_F32, 128, s);
+            } else
             k_gemm_f32(gm(m->h, 4 * Cs, st.Wred, 4 * Cs, 0, M / 4, 2 * Cs, 4 * Cs, m->stages[i + 1].blocks[0].xa, 2 * Cs), s);
         }
     }
@@ -1037,6 +1064,13 @@ static int swin_backward(vl_swin* m, float* grad_x, hipStream_t s) {
         const int nW = (Hs / WS) * (Hs / WS);
         if (i < 3) {
             // gcur = gradient w.r.t. the next stage's input [M/4, 2C]: reduction dgrad, LayerNorm backward, un-merge
+            if (m->f16) {
+                const int Mq = (int)round_up(M / 4, 128);
+                k_pack_h16(gcur, st.g16, M / 4, 2 * Cs, 2 * Cs, 0, 1.f, s);
+                GemmArgs g16a = ga(st.g16, 2 * Cs, st.WredT16, 2 * Cs, 2 * Cs, Mq, 4 * Cs);
+                g16a.Mvalid = M / 4; g16a.C = m->dbig; g16a.ldc = 4 * Cs;
+                launch_gemm(g16a, EPI_STORE_F32, 128, s);
+            } else
             k_gemm_f32(gm(gcur, 2 * Cs, st.Wred, 4 * Cs, 1, M / 4, 4 * Cs, 2 * Cs, m->dbig, 4 * Cs), s);
             k_ln_bwd_f32(m->dbig, st.mg, st.mmean, st.mrstd, st.mg_g, nullptr, m->h, M / 4, 4 * Cs, s);
             hipLaunchKernelGGL(merge_gather_kernel, dim3(nblk((int64_t)M * Cs, 256, 8192)), dim3(256), 0, s, m->h, gcur, B, Hs, Hs, Cs, 1);

@@ -160,29 +160,31 @@ def extras(P, syn, arch, args, dev, x, y):
     if args.swin:
         # BASELINE config 4: Swin-T + LoRA r = 16, PGD (fp32 first form of the windowed-attention path), batch 256
         swin = importlib.import_module(PKG + ".swin")
-        se = swin.SwinEngine(swin.SwinArch(num_labels=21), lora_r=16, lora_alpha=16.0, lora_targets=TARGETS, device=dev)
-        g = torch.Generator().manual_seed(5)
         from transformers import SwinConfig, SwinForImageClassification     # random-init weights of the architecture (no hub access)
         torch.manual_seed(0)
         hf = SwinForImageClassification(SwinConfig(num_labels=21))
-        se.load_state_dict(hf.state_dict())
-        for si, d in enumerate((2, 2, 6, 2)):
-            for bi in range(d):
-                for t in TARGETS:
-                    A, Bm = se.param(si, bi, t, "A"), se.param(si, bi, t, "B")
-                    A.copy_((torch.rand(A.shape, generator=g) * 2 - 1) / A.shape[1] ** 0.5)
-                    Bm.copy_(torch.randn(Bm.shape, generator=g) * 0.02)
-        nsw = 4
-        se.pgd_attack(x, y, EPS, ALPHA, 1, random_start=True, seed=1)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        se.pgd_attack(x, y, EPS, ALPHA, nsw, random_start=True, seed=2)
-        torch.cuda.synchronize()
-        dts = (time.perf_counter() - t0) / nsw
-        res["swin_t_lora_r16_pgd_step_f32"] = {"value": x.shape[0] / dts, "unit": "img/s per PGD step", "ms_per_pgd_step": 1e3 * dts,
-                                               "batch": int(x.shape[0]), "pgd40_img_per_s": x.shape[0] / (40 * dts), "dtype": "f32"}
-        log(f"extras: Swin-T + LoRA r=16 PGD step {1e3 * dts:.1f} ms at batch {x.shape[0]} (fp32)")
-        del se, hf
+        for prec in ("f16", "f32"):
+            se = swin.SwinEngine(swin.SwinArch(num_labels=21), lora_r=16, lora_alpha=16.0, lora_targets=TARGETS, device=dev, precision=prec)
+            g = torch.Generator().manual_seed(5)
+            se.load_state_dict(hf.state_dict())
+            for si, d in enumerate((2, 2, 6, 2)):
+                for bi in range(d):
+                    for t in TARGETS:
+                        A, Bm = se.param(si, bi, t, "A"), se.param(si, bi, t, "B")
+                        A.copy_((torch.rand(A.shape, generator=g) * 2 - 1) / A.shape[1] ** 0.5)
+                        Bm.copy_(torch.randn(Bm.shape, generator=g) * 0.02)
+            nsw = 4
+            se.pgd_attack(x, y, EPS, ALPHA, 1, random_start=True, seed=1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            se.pgd_attack(x, y, EPS, ALPHA, nsw, random_start=True, seed=2)
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - t0) / nsw
+            res["swin_t_lora_r16_pgd_step_" + prec] = {"value": x.shape[0] / dts, "unit": "img/s per PGD step", "ms_per_pgd_step": 1e3 * dts,
+                                                        "batch": int(x.shape[0]), "pgd40_img_per_s": x.shape[0] / (40 * dts), "dtype": prec}
+            log(f"extras: Swin-T + LoRA r=16 PGD step {1e3 * dts:.1f} ms at batch {x.shape[0]} ({prec})")
+            del se
+        del hf
     if args.precision == "f16":
         # the reference's own precision (whitebox_attacks.py:22-38 is fp32 end to end): the SAME PGD attack in the fp32 parity
         # mode (every operand and activation fp32, exact-f32 MFMA), priced against the f32 matrix peak

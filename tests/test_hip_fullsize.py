@@ -138,14 +138,15 @@ def test_first_attack_of_a_fresh_process_equals_its_replays():
 
 # ---- BASELINE config 4 at full size: Swin-T + LoRA r = 16, batch 256 -------------------------------------------------
 
-def test_swin_t_batch256_pgd_properties_and_shard_invariance():
+@pytest.mark.parametrize("prec", ["f16", "f32"])
+def test_swin_t_batch256_pgd_properties_and_shard_invariance(prec):
     """Swin-T + LoRA r=16 on q,k,v,o,fc2, PGD-2 on 256 images (config 4's batch; PGD-40 is the same step 40 times):
     eps-ball / pixel range, seeded determinism, and bit-exact shard invariance -- an image's trajectory does not depend on
     the batch it rides in (the 1/B of the mean loss is a power of two for both batch sizes and vanishes under sign())."""
     import test_hip_swin as TS
     m = TS.hf_swin(21, seed=23)
     ab = TS.add_lora(m, 16, 16.0, seed=25)
-    eng = TS.make_engine(m, 21, 16, ab)
+    eng = TS.make_engine(m, 21, 16, ab, precision=prec)
     g = torch.Generator().manual_seed(27)
     x = torch.rand(256, 3, 224, 224, generator=g).cuda()
     y = torch.randint(0, 21, (256,), generator=g).cuda()

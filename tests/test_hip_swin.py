@@ -104,14 +104,15 @@ def test_swin_t_logits_loss_and_input_gradient(r, prec):
         assert rel_l2(eng0.forward(x.cuda(), normalise=True).cpu(), ref_logits.detach()) > 1e-2
 
 
-def test_swin_shallow_variant_and_pgd_matches_torch_loop():
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+def test_swin_shallow_variant_and_pgd_matches_torch_loop(prec):
     """depths (1, 1, 2, 1): odd / even block positions, shifted and unshifted windows in every stage that has them; PGD-3 of
     vl_swin_pgd_attack against the same loop written with torch autograd on the HF model (canonical PGD)."""
     torch.set_num_threads(16)
     depths = (1, 2, 2, 1)
     m = hf_swin(12, seed=13, depths=depths)
     ab = add_lora(m, 8, 16.0, seed=15)
-    eng = make_engine(m, 12, 8, ab, depths=depths)
+    eng = make_engine(m, 12, 8, ab, depths=depths, precision=prec)
     g = torch.Generator().manual_seed(19)
     x = torch.rand(2, 3, 224, 224, generator=g)
     y = torch.randint(0, 12, (2,), generator=g)
@@ -123,7 +124,7 @@ def test_swin_shallow_variant_and_pgd_matches_torch_loop():
         (gr,) = torch.autograd.grad(F.cross_entropy(m((xr - MEAN) / STD).logits, y), xr)
         ref = O.pgd_step(ref, x, gr, eps, alpha)
     same = ((adv - ref).abs() < 1e-6).float().mean().item()
-    assert same > 0.999, same
+    assert same > (0.999 if prec == "f32" else 0.99), same          # 16-bit: near-zero gradient entries may flip their sign
     assert (adv - x).abs().max().item() <= eps + 1e-6 and adv.min().item() >= 0 and adv.max().item() <= 1
     # seeded random start, determinism
     a1 = eng.pgd_attack(x.cuda(), y.cuda(), eps, alpha, 2, random_start=True, seed=4)
