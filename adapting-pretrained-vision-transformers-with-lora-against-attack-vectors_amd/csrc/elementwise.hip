@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // LayerNorm backward fused with the residual-gradient add:
 //   dx = dres + rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dh * gamma
 // writes dx as f32 (residual-gradient stream) and as h16 (A operand of the next dgrad GEMM).
-template <int NV, int NG>
+template <int NV, int NG, bool PAD>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const h16* __restrict__ dh, const float* __restrict__ x,
                                                             const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                             const float* __restrict__ gamma, const float* __restrict__ dres,
@@ -193,7 +193,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const h16* __restric
     if constexpr (NG > 0) lora_down_load<NV, NG>(pr, nv, lane, P, D);
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
     const float mean = mean_in[row], rstd = rstd_in[row];
-    const int64_t off = (int64_t)row * D, offh = (int64_t)row * ldh;      // fp32 rows / h16 rows (padded stride)
+    // fp32 rows / h16 rows; PAD: the h16 rows have their own (padded) stride -- a second 64-bit offset, which costs the
+    // D = 768 fused form its fourth wave per SIMD (132 VGPRs), so the unpadded form shares one
+    const int64_t off = (int64_t)row * D, offh = PAD ? (int64_t)row * ldh : off;
     f32x4 g[NV], xh[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -228,7 +230,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const h16* __restric
                 ob[k] = f2h_sat(o[k]);
                 sat |= !(fabsf(o[k]) <= 65504.f);
             }
-            if (dx) *(f32x4*)(dx + off + c * 4) = o;       // nullptr: nobody reads the fp32 stream below (LN1 of layer 0)
+            // dx == nullptr: nobody reads the fp32 stream below (LN1 of layer 0, which never carries a fused projection;
+            // the test in the fused forms would cost them two VGPRs and with that their fourth wave per SIMD)
+            if (NG > 0 || dx) *(f32x4*)(dx + off + c * 4) = o;
             *(h16x4*)(dx_h + offh + c * 4) = ob;
             vb[i] = ob;                                              // the row as the next dgrad GEMM reads it
         }
@@ -677,9 +681,11 @@ void k_layernorm_fwd(const float* x, h16* h, float* mean, float* rstd, const flo
 template <int NV>
 static void launch_ln_bwd(dim3 grid, hipStream_t s, const h16* dh, const float* x, const float* mean, const float* rstd,
                           const float* g, const float* dres, float* dx, h16* dx_h, int M, int D, const h16* P, int ng, h16* u, int* err, int ldh) {
-    if (ng == 1) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 1>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u, err, ldh);
-    else if (ng == 2) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 2>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u, err, ldh);
-    else hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 0>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u, err, ldh);
+    if (ng > 0 && (ldh != D || !dx)) { fprintf(stderr, "vitlora: LayerNorm backward with a fused LoRA projection needs unpadded h16 rows and an fp32 output\n"); abort(); }
+    if (ng == 1) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 1, false>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u, err, ldh);
+    else if (ng == 2) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 2, false>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u, err, ldh);
+    else if (ldh != D) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 0, true>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u, err, ldh);
+    else hipLaunchKernelGGL((layernorm_bwd_kernel<NV, 0, false>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, dx, dx_h, M, D, P, u, err, ldh);
 }
 void k_layernorm_bwd(const h16* dh, const float* x, const float* mean, const float* rstd, const float* g,
                      const float* dres, float* dx, h16* dx_h, int M, int D, const h16* P, int ng, h16* u, hipStream_t s, int* err, int ldh) {

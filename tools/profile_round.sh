@@ -4,7 +4,7 @@
 #   (MI355X_MICROARCH.md: the two TCC counters do not fit one pass; FETCH_SIZE x2 on gfx950).
 # Summaries land in gpurun_out/prof_<tag>/ ; copy what is to be judged into profiles/.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
