@@ -24,6 +24,8 @@ struct GemmArgs {
     int M;            // rows computed (multiple of 128; buffers are padded to it)
     int Mvalid;       // rows that may be stored by the remapping epilogues
     int N;            // multiple of BN
+    int n_store;      // 0, or the number of leading columns that are stored (a multiple of 16 < N: the result rows are NARROWER
+                      // than the tile grid -- ldc may then be n_store; 128-row kernel only, launch_gemm routes accordingly)
     const float* bias;
     void* C; int ldc;
     void* C2; int ldc2;

@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = bn * BN + wn * (BN / 2) + j * 16 + fg * 4;
+            if (p.n_store && n >= p.n_store) continue;          // columns of the tile grid beyond the (narrower) result rows
             epilogue_store<EPI>(p, m, n, acc[i][j] + bv[j]);
         }
     }
@@ -209,11 +210,12 @@ void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
     const double mv = a.Mvalid ? a.Mvalid : a.M;
     const double flops = 2.0 * mv * (a.n_algo ? a.n_algo : a.N) * (a.K1 + (a.k2_algo ? a.k2_algo : a.K2));
     char name[64];
-    if (bn != 64 && g_force_small != 1 && gemm_pp_supports(a, epi)) {
+    const bool narrow = a.n_store > 0 && a.n_store < a.N;      // only the 128-row kernel skips columns
+    if (bn != 64 && g_force_small != 1 && !narrow && gemm_pp_supports(a, epi)) {
         launch_gemm_pp(a, epi, s);
         return;
     }
-    if (bn != 64 && g_force_small != 1 && gemm256_supports(a, epi)) {
+    if (bn != 64 && g_force_small != 1 && !narrow && gemm256_supports(a, epi)) {
         GemmArgs b = a;
         if (g_dephase >= 0) b.dephase = g_dephase;
         if (g_tile_group >= 0) b.tile_group = g_tile_group;

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/vitlora.h"
@@ -285,209 +286,357 @@ __device__ __forceinline__ f32x4 wmfma(sh16x8 a, sh16x8 b, f32x4 c) { return __b
 __device__ __forceinline__ float wgmax(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float wgsum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
 
-// stage the 49 rows of one operand of the window (row stride ld, 32 features from col0) into X[64][32], rows >= 49 zero
-__device__ __forceinline__ void wstage(h16* X, const h16* src, int ld, int col0, int b, int w, int H, int W, int shift, int lane) {
-    // 64 rows x 4 chunks of 16 bytes: lane -> (row = lane, chunk loop)
-    const int p = lane;
-    sh16x8 v[4];
+// ---- persistent form (round 3, second version) ----------------------------------------------------------------------------
+// A wave walks items gw, gw + Wn, ... (item = ((b * nW + w) * heads + hd), Wn a multiple of `heads`, so its head never
+// changes).  Everything that depends on the lane and the head only is computed ONCE per kernel and kept in registers: the
+// relative-position bias of each of the lane's 4 x 13 live score elements (pre-multiplied by log2 e: the softmax runs in
+// base 2, `v_exp_f32` is exp2), the shift-mask bit sets, the window coordinates of the lane's tokens.  The NEXT item's
+// operand rows are requested into registers before the current item is computed, so their latency hides under it.  (The
+// first version -- one item per wave -- spent 25 us per item waiting: a table gather and two integer divisions per score
+// element, every global load exposed at 1.25 waves per SIMD.)  Of the 64 padded keys only 49 exist: key tile 3 holds key 48
+// alone (lane group g = 0, element 0); its other 15 elements are never computed.
+constexpr float W16_LOG2E = 1.4426950408889634f;
+constexpr int W16_NB = 13;                   // live score elements per lane and query tile: (kt, i) for kt < 3, and (3, 0)
+struct WinLane {
+    float bias[4][W16_NB];   // table[(qy - ky + 6) * 13 + (qx - kx + 6)][hd] * log2(e) for query tile qt, element j
+    unsigned kyb, kxb;       // bit kt * 4 + i: ky >= 7 - shift, kx >= 7 - shift (region boundary inside the last window row / column)
+    unsigned qyb, qxb;       // bit qt: the same of the query
+    int tyx[4];              // (ty << 8) | tx of token t * 16 + n (clamped to 48): V / LSE rows, dQ / dK / dV / ctx rows
+    int lyx;                 // the same of token `lane` (the operand row this lane stages)
+};
+__device__ __forceinline__ WinLane win_lane(int lane, int shift, const float* __restrict__ table, int heads, int hd) {
+    WinLane L;
+    const int n = lane & 15, g = lane >> 4, th = WS - shift;
+    L.kyb = L.kxb = L.qyb = L.qxb = 0u;
+    int ky[16], kx[16];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = kt * 16 + 4 * g + i, kp = key < WT ? key : WT - 1;
+            ky[kt * 4 + i] = kp / WS; kx[kt * 4 + i] = kp - ky[kt * 4 + i] * WS;
+            if (ky[kt * 4 + i] >= th) L.kyb |= 1u << (kt * 4 + i);
+            if (kx[kt * 4 + i] >= th) L.kxb |= 1u << (kt * 4 + i);
+        }
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        const int q = qt * 16 + n, qp = q < WT ? q : WT - 1, qy = qp / WS, qx = qp - qy * WS;
+        if (qy >= th) L.qyb |= 1u << qt;
+        if (qx >= th) L.qxb |= 1u << qt;
+        L.tyx[qt] = (qy << 8) | qx;
+#pragma unroll
+        for (int j = 0; j < W16_NB; ++j)
+            L.bias[qt][j] = table[((qy - ky[j] + WS - 1) * (2 * WS - 1) + (qx - kx[j] + WS - 1)) * heads + hd] * W16_LOG2E;
+    }
+    const int lp = lane < WT ? lane : WT - 1;
+    L.lyx = ((lp / WS) << 8) | (lp % WS);
+    return L;
+}
+// keys (bit kt * 4 + i) that the shifted-window mask separates from query tile qt's query of this lane
+__device__ __forceinline__ unsigned win_mask_bits(const WinLane& L, int qt, bool edge_y, bool edge_x) {
+    unsigned m = 0u;
+    if (edge_y) m |= ((L.qyb >> qt) & 1u) ? ~L.kyb : L.kyb;
+    if (edge_x) m |= ((L.qxb >> qt) & 1u) ? ~L.kxb : L.kxb;
+    return m & 0xffffu;
+}
+// activation row of the window token whose in-window coordinates are packed in yx; (y0, x0) = window origin + shift
+__device__ __forceinline__ int64_t win_row_yx(int b, int y0, int x0, int yx, int H, int W) {
+    int y = y0 + (yx >> 8), x = x0 + (yx & 0xff);
+    if (y >= H) y -= H;
+    if (x >= W) x -= W;
+    return ((int64_t)b * H + y) * W + x;
+}
+// rows of one operand of the window as the lane will put them into an LDS tile: lane p < 49 holds its row's 32 features
+__device__ __forceinline__ void wrow_load(sh16x8 (&v)[4], const h16* src, int64_t row, int ld, int col0, bool live) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[c][k] = (h16)0.f;
-    if (p < WT) {
-        const h16* r = src + (int64_t)win_row(b, w, p, H, W, shift) * ld + col0;
+    if (live) {
+        const h16* r = src + row * ld + col0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = *(const sh16x8*)(r + 8 * c);
     }
+}
+__device__ __forceinline__ void wrow_store(h16* X, const sh16x8 (&v)[4], int p) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) *(sh16x8*)(X + wtile_off(p, 8 * c)) = v[c];
 }
+// item -> image, window origin (+ shift), edge flags
+struct WinItem { int b, y0, x0; bool edge_y, edge_x; };
+__device__ __forceinline__ WinItem win_item(int64_t item, int heads, int nW, int nwx, int nwy, int shift) {
+    const int64_t bw = item / heads;
+    WinItem it;
+    it.b = (int)(bw / nW);
+    const int w = (int)(bw - (int64_t)it.b * nW), wy = w / nwx, wx = w - wy * nwx;
+    it.y0 = wy * WS + shift; it.x0 = wx * WS + shift;
+    it.edge_y = shift && wy == nwy - 1; it.edge_x = shift && wx == nwx - 1;
+    return it;
+}
+__device__ __forceinline__ float wexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-constexpr int W16_FWD_WAVES = 4;
-__global__ __launch_bounds__(64 * W16_FWD_WAVES) void win16_fwd_kernel(const h16* __restrict__ qkv, int ldq, const float* __restrict__ table,
-                                                                       h16* __restrict__ ctx, int ldc, float* __restrict__ lse, int B, int H,
-                                                                       int W, int C, int heads, int shift) {
-    __shared__ __attribute__((aligned(16))) h16 sm[W16_FWD_WAVES][3][W16T * HDIM];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int nW = (H / WS) * (W / WS);
-    const int64_t item = (int64_t)blockIdx.x * W16_FWD_WAVES + wv;
-    if (item >= (int64_t)B * nW * heads) return;
-    const int hd = (int)(item % heads);
-    const int w = (int)((item / heads) % nW);
-    const int b = (int)(item / ((int64_t)heads * nW));
-    h16 *sQ = sm[wv][0], *sK = sm[wv][1], *sV = sm[wv][2];
-    wstage(sQ, qkv, ldq, hd * HDIM, b, w, H, W, shift, lane);
-    wstage(sK, qkv, ldq, C + hd * HDIM, b, w, H, W, shift, lane);
-    wstage(sV, qkv, ldq, 2 * C + hd * HDIM, b, w, H, W, shift, lane);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+// LSE is kept in BASE 2 (log2 of the row sum of 2^(a log2 e)): the backward consumes it as it is
+__global__ __launch_bounds__(64) void win16_fwd_kernel(const h16* __restrict__ qkv, int ldq, const float* __restrict__ table,
+                                                       h16* __restrict__ ctx, int ldc, float* __restrict__ lse, int B, int H,
+                                                       int W, int C, int heads, int shift, int64_t items) {
+    __shared__ __attribute__((aligned(16))) h16 sm[3 * W16T * HDIM];
+    const int lane = threadIdx.x;
+    const int nwx = W / WS, nwy = H / WS, nW = nwy * nwx;
+    const int64_t Wn = gridDim.x;
+    const int hd = (int)(blockIdx.x % heads);
+    h16 *sQ = sm, *sK = sm + W16T * HDIM, *sV = sK + W16T * HDIM;
+    const WinLane L = win_lane(lane, shift, table, heads, hd);
     const int n = lane & 15, g = lane >> 4;
-    const float scale = 0.17677669529663687f;
+    const float scale2 = 0.17677669529663687f * W16_LOG2E;
+    const bool live = lane < WT;
+    sh16x8 pq[4], pk[4], pv[4];
+    int64_t item = blockIdx.x;
+    WinItem it = win_item(item, heads, nW, nwx, nwy, shift);
+    auto request = [&]() {
+        const int64_t row = win_row_yx(it.b, it.y0, it.x0, L.lyx, H, W);
+        wrow_load(pq, qkv, row, ldq, hd * HDIM, live);
+        wrow_load(pk, qkv, row, ldq, C + hd * HDIM, live);
+        wrow_load(pv, qkv, row, ldq, 2 * C + hd * HDIM, live);
+    };
+    request();
 #pragma unroll 1
-    for (int qt = 0; qt < 4; ++qt) {
-        const int q = qt * 16 + n;                    // this lane's query (window position)
-        const int qp = q < WT ? q : WT - 1;
-        const int reg_q = shift ? win_region(w, qp, H, W, shift) : 0;
-        const sh16x8 qf = wfrag_row(sQ, qt * 16, lane);
-        f32x4 st[4];
-        float mx = -INFINITY;
+    for (; item < items; item += Wn) {
+        wrow_store(sQ, pq, lane);
+        wrow_store(sK, pk, lane);
+        wrow_store(sV, pv, lane);
+        const WinItem cur = it;
+        if (item + Wn < items) {                                    // next item's rows: in flight under this item's work
+            it = win_item(item + Wn, heads, nW, nwx, nwy, shift);
+            request();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        auto body = [&](auto edge_c) {
+            constexpr bool EDGE = decltype(edge_c)::value;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            st[kt] = wmfma(wfrag_row(sK, kt * 16, lane), qf, f32x4{0.f, 0.f, 0.f, 0.f});        // S^T[key][q]
+            for (int qt = 0; qt < 4; ++qt) {
+                const int q = qt * 16 + n;
+                const unsigned mbits = EDGE ? win_mask_bits(L, qt, cur.edge_y, cur.edge_x) : 0u;
+                const sh16x8 qf = wfrag_row(sQ, qt * 16, lane);
+                f32x4 st[4];
+                float mx = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int key = kt * 16 + 4 * g + i;
-                float a = -INFINITY;
-                if (key < WT) {
-                    a = st[kt][i] * scale + table[bias_index(qp, key) * heads + hd];
-                    if (shift && win_region(w, key, H, W, shift) != reg_q) a += -100.0f;
+                for (int kt = 0; kt < 4; ++kt) {
+                    st[kt] = wmfma(wfrag_row(sK, kt * 16, lane), qf, f32x4{0.f, 0.f, 0.f, 0.f});        // S^T[key][q]
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (kt == 3 && i > 0) { st[kt][i] = -INFINITY; continue; }                       // keys 49..63 do not exist
+                        const int j = kt * 4 + i;
+                        float a = fmaf(st[kt][i], scale2, L.bias[qt][j]);
+                        if (EDGE && ((mbits >> j) & 1u)) a += -100.0f * W16_LOG2E;
+                        if (kt == 3 && g != 0) a = -INFINITY;                                            // key 48 + 4g
+                        st[kt][i] = a;
+                        mx = fmaxf(mx, a);
+                    }
                 }
-                st[kt][i] = a;
-                mx = fmaxf(mx, a);
+                mx = wgmax(mx);
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (kt == 3 && i > 0) { st[kt][i] = 0.f; continue; }
+                        st[kt][i] = wexp2(st[kt][i] - mx);
+                        sum += st[kt][i];
+                    }
+                sum = wgsum(sum);
+                f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    sh16x8 pb;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { pb[j] = f2h(st[2 * a][j]); pb[4 + j] = f2h(st[2 * a + 1][j]); }
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) o[dt] = wmfma(wfrag_tok_tile(sV, 32 * a, dt * 16, lane), pb, o[dt]);   // O^T[d][q]
+                }
+                if (q < WT) {
+                    const float inv = 1.f / sum;
+                    const int64_t row = win_row_yx(cur.b, cur.y0, cur.x0, L.tyx[qt], H, W);
+                    h16* dst = ctx + row * ldc + hd * HDIM;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        sh16x4 ov;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ov[i] = f2h(o[dt][i] * inv);
+                        *(sh16x4*)(dst + dt * 16 + 4 * g) = ov;
+                    }
+                    if (g == 0) lse[row * heads + hd] = mx + __log2f(sum);
+                }
             }
-        }
-        mx = wgmax(mx);
-        float sum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { st[kt][i] = expf(st[kt][i] - mx); sum += st[kt][i]; }
-        sum = wgsum(sum);
-        f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            sh16x8 pb;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { pb[j] = f2h(st[2 * a][j]); pb[4 + j] = f2h(st[2 * a + 1][j]); }
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) o[dt] = wmfma(wfrag_tok_tile(sV, 32 * a, dt * 16, lane), pb, o[dt]);   // O^T[d][q]
-        }
-        if (q < WT) {
-            const float inv = 1.f / sum;
-            const int row = win_row(b, w, q, H, W, shift);
-            h16* dst = ctx + (int64_t)row * ldc + hd * HDIM;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                sh16x4 ov;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) ov[i] = f2h(o[dt][i] * inv);
-                *(sh16x4*)(dst + dt * 16 + 4 * g) = ov;
-            }
-            if (g == 0) lse[(int64_t)row * heads + hd] = mx + logf(sum);
-        }
+        };
+        if (cur.edge_y || cur.edge_x) body(std::true_type{}); else body(std::false_type{});
     }
 }
 
-constexpr int W16_BWD_WAVES = 1;          // 32 KiB of LDS per wave: one wave per workgroup lets five of them share a CU
 constexpr int PLD = 64;                  // row stride of the P / dS images ([q][key] h16)
-__global__ __launch_bounds__(64 * W16_BWD_WAVES) void win16_bwd_kernel(const h16* __restrict__ qkv, int ldq, const float* __restrict__ table,
-                                                                       const h16* __restrict__ dctx, int ldc, const float* __restrict__ lse,
-                                                                       h16* __restrict__ dqkv, int B, int H, int W, int C, int heads,
-                                                                       int shift) {
-    __shared__ __attribute__((aligned(16))) h16 sm[W16_BWD_WAVES][4 * W16T * HDIM + 2 * W16T * PLD];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int nW = (H / WS) * (W / WS);
-    const int64_t item = (int64_t)blockIdx.x * W16_BWD_WAVES + wv;
-    if (item >= (int64_t)B * nW * heads) return;
-    const int hd = (int)(item % heads);
-    const int w = (int)((item / heads) % nW);
-    const int b = (int)(item / ((int64_t)heads * nW));
-    h16 *sQ = sm[wv], *sK = sQ + W16T * HDIM, *sV = sK + W16T * HDIM, *sdO = sV + W16T * HDIM;
-    h16 *sP = sdO + W16T * HDIM, *sdS = sP + W16T * PLD;
-    wstage(sQ, qkv, ldq, hd * HDIM, b, w, H, W, shift, lane);
-    wstage(sK, qkv, ldq, C + hd * HDIM, b, w, H, W, shift, lane);
-    wstage(sV, qkv, ldq, 2 * C + hd * HDIM, b, w, H, W, shift, lane);
-    wstage(sdO, dctx, ldc, hd * HDIM, b, w, H, W, shift, lane);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+// LDS per wave: Q, K, dO tiles (V is only ever read as row fragments: straight from global memory) + the P and dS images
+// = 28 KiB; the kernel runs one wave per SIMD (its registers: 64 of prefetch, 52 of bias), four workgroups per CU
+__global__ __launch_bounds__(64) void win16_bwd_kernel(const h16* __restrict__ qkv, int ldq, const float* __restrict__ table,
+                                                       const h16* __restrict__ dctx, int ldc, const float* __restrict__ lse,
+                                                       h16* __restrict__ dqkv, int B, int H, int W, int C, int heads,
+                                                       int shift, int64_t items) {
+    __shared__ __attribute__((aligned(16))) h16 sm[3 * W16T * HDIM + 2 * W16T * PLD];
+    const int lane = threadIdx.x;
+    const int nwx = W / WS, nwy = H / WS, nW = nwy * nwx;
+    const int64_t Wn = gridDim.x;
+    const int hd = (int)(blockIdx.x % heads);
+    h16 *sQ = sm, *sK = sQ + W16T * HDIM, *sdO = sK + W16T * HDIM, *sP = sdO + W16T * HDIM, *sdS = sP + W16T * PLD;
+    const WinLane L = win_lane(lane, shift, table, heads, hd);
     const int n = lane & 15, g = lane >> 4;
-    const float scale = 0.17677669529663687f;
-    // ---- per query tile: P^T, dS^T (keys on the rows); dQ from them directly, P / dS also into the [q][key] images ----
+    const float scale = 0.17677669529663687f, scale2 = scale * W16_LOG2E;
+    const bool live = lane < WT;
+    sh16x8 pq[4], pk[4], pd[4], pvf[4];
+    float plse[4];
+    int64_t prow[4];
+    int64_t item = blockIdx.x;
+    WinItem it = win_item(item, heads, nW, nwx, nwy, shift);
+    auto request = [&]() {
+        const int64_t row = win_row_yx(it.b, it.y0, it.x0, L.lyx, H, W);
+        wrow_load(pq, qkv, row, ldq, hd * HDIM, live);
+        wrow_load(pk, qkv, row, ldq, C + hd * HDIM, live);
+        wrow_load(pd, dctx, row, ldc, hd * HDIM, live);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool lv = t * 16 + n < WT;                            // V row fragment of key tile t / LSE of query tile t
+            prow[t] = win_row_yx(it.b, it.y0, it.x0, L.tyx[t], H, W);   // (clamped token: always a valid row)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pvf[t][k] = (h16)0.f;
+            if (lv) pvf[t] = *(const sh16x8*)(qkv + prow[t] * ldq + 2 * C + hd * HDIM + 8 * g);
+            plse[t] = lv ? lse[prow[t] * heads + hd] : INFINITY;        // rows >= 49: P = 0
+        }
+    };
+    request();
 #pragma unroll 1
-    for (int qt = 0; qt < 4; ++qt) {
-        const int q = qt * 16 + n;
-        const int qp = q < WT ? q : WT - 1;
-        const int reg_q = shift ? win_region(w, qp, H, W, shift) : 0;
-        const float lq = q < WT ? lse[(int64_t)win_row(b, w, qp, H, W, shift) * heads + hd] : INFINITY;     // rows >= 49: P = 0
-        const sh16x8 qf = wfrag_row(sQ, qt * 16, lane), dof = wfrag_row(sdO, qt * 16, lane);
-        f32x4 p[4], dp[4];
-        float dsum = 0.f;
+    for (; item < items; item += Wn) {
+        wrow_store(sQ, pq, lane);
+        wrow_store(sK, pk, lane);
+        wrow_store(sdO, pd, lane);
+        // REAL copies (v_mov the compiler cannot fold away): the item works on registers that are not load destinations, so
+        // every wait on the previous request sits here, before the next one is issued -- vmcnt is in order, and a wait for
+        // an old load inside the item's work would also wait for the first of the new ones
+        sh16x8 vf[4];
+        float lq[4];
+        int64_t crow[4];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            p[kt] = wmfma(wfrag_row(sK, kt * 16, lane), qf, f32x4{0.f, 0.f, 0.f, 0.f});          // S^T[key][q]
-            dp[kt] = wmfma(wfrag_row(sV, kt * 16, lane), dof, f32x4{0.f, 0.f, 0.f, 0.f});        // dP^T[key][q]
+        for (int t = 0; t < 4; ++t) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 src = __builtin_bit_cast(u32x4, pvf[t]);
+            u32x4 dstv;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int key = kt * 16 + 4 * g + i;
-                float pv = 0.f;
-                if (key < WT) {
-                    float a = p[kt][i] * scale + table[bias_index(qp, key) * heads + hd];
-                    if (shift && win_region(w, key, H, W, shift) != reg_q) a += -100.0f;
-                    pv = expf(a - lq);
+            for (int k = 0; k < 4; ++k) { unsigned o; asm volatile("v_mov_b32 %0, %1" : "=v"(o) : "v"(src[k])); dstv[k] = o; }
+            vf[t] = __builtin_bit_cast(sh16x8, dstv);
+            asm volatile("v_mov_b32 %0, %1" : "=v"(lq[t]) : "v"(plse[t]));
+            crow[t] = prow[t];
+        }
+        const WinItem cur = it;
+        if (item + Wn < items) {
+            it = win_item(item + Wn, heads, nW, nwx, nwy, shift);
+            request();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ---- per query tile: P^T, dS^T (keys on the rows); dQ from them directly, P / dS also into the [q][key] images ----
+        auto body = [&](auto edge_c) {
+            constexpr bool EDGE = decltype(edge_c)::value;
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                const int q = qt * 16 + n;
+                const unsigned mbits = EDGE ? win_mask_bits(L, qt, cur.edge_y, cur.edge_x) : 0u;
+                const sh16x8 qf = wfrag_row(sQ, qt * 16, lane), dof = wfrag_row(sdO, qt * 16, lane);
+                f32x4 p[4], dp[4];
+                float dsum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    p[kt] = wmfma(wfrag_row(sK, kt * 16, lane), qf, f32x4{0.f, 0.f, 0.f, 0.f});          // S^T[key][q]
+                    dp[kt] = wmfma(vf[kt], dof, f32x4{0.f, 0.f, 0.f, 0.f});                              // dP^T[key][q]
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (kt == 3 && i > 0) { p[kt][i] = 0.f; dp[kt][i] = 0.f; continue; }              // keys 49..63 do not exist
+                        const int j = kt * 4 + i;
+                        float a = fmaf(p[kt][i], scale2, L.bias[qt][j]);
+                        if (EDGE && ((mbits >> j) & 1u)) a += -100.0f * W16_LOG2E;
+                        float pv = wexp2(a - lq[qt]);
+                        if (kt == 3 && g != 0) pv = 0.f;                                                  // key 48 + 4g
+                        p[kt][i] = pv;
+                        dsum = fmaf(pv, dp[kt][i], dsum);
+                    }
                 }
-                p[kt][i] = pv;
-                dsum = fmaf(pv, dp[kt][i], dsum);
+                const float delta = wgsum(dsum);                 // rowsum(P * dP) = rowsum(dO * O)
+                f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    sh16x4 p4, d4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (kt == 3 && i > 0) { p4[i] = (h16)0.f; d4[i] = (h16)0.f; continue; }
+                        dp[kt][i] = p[kt][i] * (dp[kt][i] - delta) * scale;        // dS^T
+                        p4[i] = f2h(p[kt][i]);
+                        d4[i] = f2h_sat(dp[kt][i]);
+                    }
+                    // images [q][key]: this lane's query row, keys 16kt + 4g .. +3
+                    *(sh16x4*)(sP + wimg_off(q, kt * 16 + 4 * g)) = p4;
+                    *(sh16x4*)(sdS + wimg_off(q, kt * 16 + 4 * g)) = d4;
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    sh16x8 db;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { db[j] = f2h_sat(dp[2 * a][j]); db[4 + j] = f2h_sat(dp[2 * a + 1][j]); }
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) dq[dt] = wmfma(wfrag_tok_tile(sK, 32 * a, dt * 16, lane), db, dq[dt]);   // dQ^T[d][q]
+                }
+                if (q < WT) {
+                    h16* dst = dqkv + crow[qt] * ldq + hd * HDIM;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        sh16x4 ov;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ov[i] = f2h_sat(dq[dt][i]);
+                        *(sh16x4*)(dst + dt * 16 + 4 * g) = ov;
+                    }
+                }
             }
-        }
-        const float delta = wgsum(dsum);                 // rowsum(P * dP) = rowsum(dO * O)
-        f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        };
+        if (cur.edge_y || cur.edge_x) body(std::true_type{}); else body(std::false_type{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ---- per key tile: dV^T[d][key] = sum_q dO^T[d][q] P[q][key], dK^T[d][key] = sum_q Q^T[d][q] dS[q][key] ----
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            sh16x4 p4, d4;
+            const int key = kt * 16 + n;
+            f32x4 dv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, dk[2] = {dv[0], dv[0]};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                dp[kt][i] = p[kt][i] * (dp[kt][i] - delta) * scale;        // dS^T
-                p4[i] = f2h(p[kt][i]);
-                d4[i] = f2h_sat(dp[kt][i]);
+            for (int a = 0; a < 2; ++a) {
+                const sh16x8 pb = wfrag_tok_img(sP, 32 * a, kt * 16, lane), db = wfrag_tok_img(sdS, 32 * a, kt * 16, lane);   // k = query, n = key
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dv[dt] = wmfma(wfrag_tok_tile(sdO, 32 * a, dt * 16, lane), pb, dv[dt]);
+                    dk[dt] = wmfma(wfrag_tok_tile(sQ, 32 * a, dt * 16, lane), db, dk[dt]);
+                }
             }
-            // images [q][key]: this lane's query row, keys 16kt + 4g .. +3
-            *(sh16x4*)(sP + wimg_off(q, kt * 16 + 4 * g)) = p4;
-            *(sh16x4*)(sdS + wimg_off(q, kt * 16 + 4 * g)) = d4;
-        }
+            if (key < WT) {
+                h16* dst = dqkv + crow[kt] * ldq + hd * HDIM;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            sh16x8 db;
+                for (int dt = 0; dt < 2; ++dt) {
+                    sh16x4 kv, vv;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { db[j] = f2h_sat(dp[2 * a][j]); db[4 + j] = f2h_sat(dp[2 * a + 1][j]); }
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) dq[dt] = wmfma(wfrag_tok_tile(sK, 32 * a, dt * 16, lane), db, dq[dt]);   // dQ^T[d][q]
-        }
-        if (q < WT) {
-            h16* dst = dqkv + (int64_t)win_row(b, w, q, H, W, shift) * ldq + hd * HDIM;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                sh16x4 ov;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) ov[i] = f2h_sat(dq[dt][i]);
-                *(sh16x4*)(dst + dt * 16 + 4 * g) = ov;
+                    for (int i = 0; i < 4; ++i) { kv[i] = f2h_sat(dk[dt][i]); vv[i] = f2h_sat(dv[dt][i]); }
+                    *(sh16x4*)(dst + C + dt * 16 + 4 * g) = kv;
+                    *(sh16x4*)(dst + 2 * C + dt * 16 + 4 * g) = vv;
+                }
             }
         }
+        // the next item's LDS writes follow this item's last LDS reads in program order of the one wave: no barrier needed
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // ---- per key tile: dV^T[d][key] = sum_q dO^T[d][q] P[q][key], dK^T[d][key] = sum_q Q^T[d][q] dS[q][key] ----
-#pragma unroll 1
-    for (int kt = 0; kt < 4; ++kt) {
-        const int key = kt * 16 + n;
-        f32x4 dv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, dk[2] = {dv[0], dv[0]};
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const sh16x8 pb = wfrag_tok_img(sP, 32 * a, kt * 16, lane), db = wfrag_tok_img(sdS, 32 * a, kt * 16, lane);   // k = query, n = key
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                dv[dt] = wmfma(wfrag_tok_tile(sdO, 32 * a, dt * 16, lane), pb, dv[dt]);
-                dk[dt] = wmfma(wfrag_tok_tile(sQ, 32 * a, dt * 16, lane), db, dk[dt]);
-            }
-        }
-        if (key < WT) {
-            h16* dst = dqkv + (int64_t)win_row(b, w, key, H, W, shift) * ldq + hd * HDIM;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                sh16x4 kv, vv;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { kv[i] = f2h_sat(dk[dt][i]); vv[i] = f2h_sat(dv[dt][i]); }
-                *(sh16x4*)(dst + C + dt * 16 + 4 * g) = kv;
-                *(sh16x4*)(dst + 2 * C + dt * 16 + 4 * g) = vv;
-            }
-        }
-    }
+}
+
+// persistent grid of the window kernels: `per_cu` single-wave workgroups per CU, a multiple of `heads`, at most one per item
+inline unsigned win16_grid(int64_t items, int heads, int per_cu) {
+    int64_t wn = (int64_t)256 * per_cu / heads * heads;
+    if (wn > items) wn = items;          // items is a multiple of heads
+    return (unsigned)wn;
 }
 
 // out[b][i] = x[b][i] * f[b]  (per-image power-of-two gradient scale of the 16-bit backward and its inverse)
@@ -526,7 +675,11 @@ struct SStage {
     float *mg_g = nullptr, *mg_b = nullptr, *Wred = nullptr;
     float *mg = nullptr, *mmean = nullptr, *mrstd = nullptr;    // saved
     // 16-bit path: per-stage scratch (strides are the stage's own padded widths: pad columns stay zero for ever)
-    int CP = 0, C3P = 0, C4P = 0;
+    int CP = 0, C3P = 0, C4P = 0;             // GEMM dims: C, 3C, 4C rounded up to the 128-wide tiles (weights are zero padded)
+    int LC = 0, L3 = 0, L4 = 0;               // row strides of the h16 activations: the padded dims, or C, 3C, 4C themselves
+                                              // (stage 1: 96 / 288 / 384 -- a quarter fewer bytes on every tensor of the HBM-bound
+                                              // stage; the GEMM then reads its last K columns from the NEXT row, times zero weights,
+                                              // and skips the stores of the tile grid's extra columns: GemmArgs.n_store)
     h16 *h16b = nullptr, *a16 = nullptr, *delta16 = nullptr, *ctx16 = nullptr, *t16 = nullptr, *u16 = nullptr;
     h16 *dz16 = nullptr, *dqkv16 = nullptr, *dh16 = nullptr, *dctx16 = nullptr, *gh16 = nullptr;
     h16 *Wred16 = nullptr, *WredT16 = nullptr, *mg16 = nullptr, *g16 = nullptr;     // patch-merging reduction on h16 operands
@@ -553,6 +706,7 @@ struct vl_swin {
     float *gscale = nullptr, *inv_gscale = nullptr, *dlogits_s = nullptr;
     int f16 = 0;             // cfg.reserved[0] == 1: 16-bit operand path for the blocks (embedding, merging and head stay fp32)
     int dirty = 1;           // packed h16 operands are stale (weights / adapters written since the last commit)
+    int unpad_stages = 1;    // bit i: stage i keeps its h16 activations at their true width (VITLORA_SWIN_UNPAD; default: stage 1 only)
 };
 
 namespace {
@@ -636,11 +790,12 @@ void swin16_commit(vl_swin* m, hipStream_t s) {
 }
 
 // y = x W^T + b (+ LoRA as one extra K tile), epilogue `epi`; x [Mp][inP] h16
-void lin16_fwd(vl_swin* m, SStage& st, const SLin& ln, const h16* x, int Mp, int M, GemmArgs g, int epi, hipStream_t s) {
-    g.A1 = x; g.lda1 = ln.inP; g.W1 = ln.W16; g.ldw1 = ln.inP; g.K1 = ln.inP;
+void lin16_fwd(vl_swin* m, SStage& st, const SLin& ln, const h16* x, int ldx, int Mp, int M, GemmArgs g, int epi, hipStream_t s) {
+    g.A1 = x; g.lda1 = ldx; g.W1 = ln.W16; g.ldw1 = ln.inP; g.K1 = ln.inP;
     g.M = Mp; g.Mvalid = M; g.N = ln.outP; g.bias = ln.b16;
+    g.n_store = g.ldc < ln.outP ? ln.out : 0;                      // unpadded result rows (ldc = out)
     if (ln.kext) {
-        GemmArgs d = ga(x, ln.inP, ln.Ad, ln.inP, ln.inP, Mp, 64);
+        GemmArgs d = ga(x, ldx, ln.Ad, ln.inP, ln.inP, Mp, 64);
         d.Mvalid = M; d.C = st.t16; d.ldc = 64; d.n_algo = m->r * (int)ln.slots.size();
         launch_gemm(d, EPI_STORE_H16, 64, s);
         g.A2 = st.t16; g.lda2 = 64; g.W2 = ln.Bu; g.ldw2 = 64; g.K2 = 64;
@@ -649,11 +804,12 @@ void lin16_fwd(vl_swin* m, SStage& st, const SLin& ln, const h16* x, int Mp, int
     launch_gemm(g, epi, 128, s);
 }
 // dx = dy W (+ LoRA), dy [Mp][outP] h16
-void lin16_dgrad(vl_swin* m, SStage& st, const SLin& ln, const h16* dy, int Mp, int M, GemmArgs g, int epi, hipStream_t s) {
-    g.A1 = dy; g.lda1 = ln.outP; g.W1 = ln.WT16; g.ldw1 = ln.outP; g.K1 = ln.outP;
+void lin16_dgrad(vl_swin* m, SStage& st, const SLin& ln, const h16* dy, int ldy, int Mp, int M, GemmArgs g, int epi, hipStream_t s) {
+    g.A1 = dy; g.lda1 = ldy; g.W1 = ln.WT16; g.ldw1 = ln.outP; g.K1 = ln.outP;
     g.M = Mp; g.Mvalid = M; g.N = ln.inP; g.bias = nullptr;
+    g.n_store = g.ldc < ln.inP ? ln.in : 0;
     if (ln.kext) {
-        GemmArgs d = ga(dy, ln.outP, ln.Bd, ln.outP, ln.outP, Mp, 64);
+        GemmArgs d = ga(dy, ldy, ln.Bd, ln.outP, ln.outP, Mp, 64);
         d.Mvalid = M; d.C = st.u16; d.ldc = 64; d.n_algo = m->r;
         launch_gemm(d, EPI_STORE_H16, 64, s);
         g.A2 = st.u16; g.lda2 = 64; g.W2 = ln.Au; g.ldw2 = 64; g.K2 = 64;
@@ -670,20 +826,21 @@ void swin16_block_fwd(vl_swin* m, SStage& st, SBlock& bk, const float* x_prev, b
     const int nW = (Hs / WS) * (Hs / WS);
     GemmArgs g;
     // LayerNorm 1 (+ residual add of the previous block's MLP output: x_prev + delta -> bk.xa)
-    if (add_delta) k_layernorm_fwd(x_prev, st.h16b, bk.mean1, bk.rstd1, bk.ln1_g, bk.ln1_b, M, Cs, m->cfg.ln_eps, st.delta16, bk.xa, nullptr, 0, nullptr, s, st.CP);
-    else k_layernorm_fwd(bk.xa, st.h16b, bk.mean1, bk.rstd1, bk.ln1_g, bk.ln1_b, M, Cs, m->cfg.ln_eps, nullptr, nullptr, nullptr, 0, nullptr, s, st.CP);
-    memset(&g, 0, sizeof g); g.C = bk.qkv16; g.ldc = st.C3P;
-    lin16_fwd(m, st, bk.qkv, st.h16b, Mp, M, g, EPI_STORE_H16, s);
-    hipLaunchKernelGGL(win16_fwd_kernel, dim3(nblk((int64_t)B * nW * st.heads, W16_FWD_WAVES, 1 << 30)), dim3(64 * W16_FWD_WAVES), 0, s,
-                       bk.qkv16, st.C3P, bk.table, st.ctx16, st.CP, bk.lse, B, Hs, Hs, Cs, st.heads, shift);
-    memset(&g, 0, sizeof g); g.C = st.delta16; g.ldc = st.CP;
-    lin16_fwd(m, st, bk.o, st.ctx16, Mp, M, g, EPI_STORE_H16, s);
+    if (add_delta) k_layernorm_fwd(x_prev, st.h16b, bk.mean1, bk.rstd1, bk.ln1_g, bk.ln1_b, M, Cs, m->cfg.ln_eps, st.delta16, bk.xa, nullptr, 0, nullptr, s, st.LC);
+    else k_layernorm_fwd(bk.xa, st.h16b, bk.mean1, bk.rstd1, bk.ln1_g, bk.ln1_b, M, Cs, m->cfg.ln_eps, nullptr, nullptr, nullptr, 0, nullptr, s, st.LC);
+    memset(&g, 0, sizeof g); g.C = bk.qkv16; g.ldc = st.L3;
+    lin16_fwd(m, st, bk.qkv, st.h16b, st.LC, Mp, M, g, EPI_STORE_H16, s);
+    const int64_t witems = (int64_t)B * nW * st.heads;
+    hipLaunchKernelGGL(win16_fwd_kernel, dim3(win16_grid(witems, st.heads, 8)), dim3(64), 0, s,
+                       bk.qkv16, st.L3, bk.table, st.ctx16, st.LC, bk.lse, B, Hs, Hs, Cs, st.heads, shift, witems);
+    memset(&g, 0, sizeof g); g.C = st.delta16; g.ldc = st.LC;
+    lin16_fwd(m, st, bk.o, st.ctx16, st.LC, Mp, M, g, EPI_STORE_H16, s);
     // LayerNorm 2 (+ residual add of the attention output: bk.xa + delta -> bk.xb)
-    k_layernorm_fwd(bk.xa, st.h16b, bk.mean2, bk.rstd2, bk.ln2_g, bk.ln2_b, M, Cs, m->cfg.ln_eps, st.delta16, bk.xb, nullptr, 0, nullptr, s, st.CP);
-    memset(&g, 0, sizeof g); g.C = st.a16; g.ldc = st.C4P; g.C2 = bk.z16; g.ldc2 = st.C4P;
-    lin16_fwd(m, st, bk.fc1, st.h16b, Mp, M, g, EPI_GELU, s);
-    memset(&g, 0, sizeof g); g.C = st.delta16; g.ldc = st.CP;
-    lin16_fwd(m, st, bk.fc2, st.a16, Mp, M, g, EPI_STORE_H16, s);
+    k_layernorm_fwd(bk.xa, st.h16b, bk.mean2, bk.rstd2, bk.ln2_g, bk.ln2_b, M, Cs, m->cfg.ln_eps, st.delta16, bk.xb, nullptr, 0, nullptr, s, st.LC);
+    memset(&g, 0, sizeof g); g.C = st.a16; g.ldc = st.L4; g.C2 = bk.z16; g.ldc2 = st.L4;
+    lin16_fwd(m, st, bk.fc1, st.h16b, st.LC, Mp, M, g, EPI_GELU, s);
+    memset(&g, 0, sizeof g); g.C = st.delta16; g.ldc = st.LC;
+    lin16_fwd(m, st, bk.fc2, st.a16, st.L4, Mp, M, g, EPI_STORE_H16, s);
 }
 
 // One Swin block, backward.  gin (fp32 [M, C]) / st.gh16 (its h16 copy): gradient w.r.t. the block's output stream;
@@ -692,18 +849,19 @@ void swin16_block_bwd(vl_swin* m, SStage& st, SBlock& bk, const float* gin, floa
     const int Cs = st.C, Hs = st.H, M = B * Hs * Hs, Mp = (int)round_up(M, 128);
     const int nW = (Hs / WS) * (Hs / WS);
     GemmArgs g;
-    memset(&g, 0, sizeof g); g.C = st.dz16; g.ldc = st.C4P; g.R = bk.z16; g.ldr = st.C4P;
-    lin16_dgrad(m, st, bk.fc2, st.gh16, Mp, M, g, EPI_GELU_BWD, s);                         // d(z) = (d(out) Wfc2) * gelu'(z)
-    memset(&g, 0, sizeof g); g.C = st.dh16; g.ldc = st.CP;
-    lin16_dgrad(m, st, bk.fc1, st.dz16, Mp, M, g, EPI_STORE_H16, s);
-    k_layernorm_bwd(st.dh16, bk.xb, bk.mean2, bk.rstd2, bk.ln2_g, gin, gmid, st.gh16, M, Cs, nullptr, 0, nullptr, s, m->err_flag, st.CP);
-    memset(&g, 0, sizeof g); g.C = st.dctx16; g.ldc = st.CP;
-    lin16_dgrad(m, st, bk.o, st.gh16, Mp, M, g, EPI_STORE_H16, s);
-    hipLaunchKernelGGL(win16_bwd_kernel, dim3(nblk((int64_t)B * nW * st.heads, W16_BWD_WAVES, 1 << 30)), dim3(64 * W16_BWD_WAVES), 0, s,
-                       bk.qkv16, st.C3P, bk.table, st.dctx16, st.CP, bk.lse, st.dqkv16, B, Hs, Hs, Cs, st.heads, shift);
-    memset(&g, 0, sizeof g); g.C = st.dh16; g.ldc = st.CP;
-    lin16_dgrad(m, st, bk.qkv, st.dqkv16, Mp, M, g, EPI_STORE_H16, s);
-    k_layernorm_bwd(st.dh16, bk.xa, bk.mean1, bk.rstd1, bk.ln1_g, gmid, gout, st.gh16, M, Cs, nullptr, 0, nullptr, s, m->err_flag, st.CP);
+    memset(&g, 0, sizeof g); g.C = st.dz16; g.ldc = st.L4; g.R = bk.z16; g.ldr = st.L4;
+    lin16_dgrad(m, st, bk.fc2, st.gh16, st.LC, Mp, M, g, EPI_GELU_BWD, s);                         // d(z) = (d(out) Wfc2) * gelu'(z)
+    memset(&g, 0, sizeof g); g.C = st.dh16; g.ldc = st.LC;
+    lin16_dgrad(m, st, bk.fc1, st.dz16, st.L4, Mp, M, g, EPI_STORE_H16, s);
+    k_layernorm_bwd(st.dh16, bk.xb, bk.mean2, bk.rstd2, bk.ln2_g, gin, gmid, st.gh16, M, Cs, nullptr, 0, nullptr, s, m->err_flag, st.LC);
+    memset(&g, 0, sizeof g); g.C = st.dctx16; g.ldc = st.LC;
+    lin16_dgrad(m, st, bk.o, st.gh16, st.LC, Mp, M, g, EPI_STORE_H16, s);
+    const int64_t witems = (int64_t)B * nW * st.heads;
+    hipLaunchKernelGGL(win16_bwd_kernel, dim3(win16_grid(witems, st.heads, 4)), dim3(64), 0, s,
+                       bk.qkv16, st.L3, bk.table, st.dctx16, st.LC, bk.lse, st.dqkv16, B, Hs, Hs, Cs, st.heads, shift, witems);
+    memset(&g, 0, sizeof g); g.C = st.dh16; g.ldc = st.LC;
+    lin16_dgrad(m, st, bk.qkv, st.dqkv16, st.L3, Mp, M, g, EPI_STORE_H16, s);
+    k_layernorm_bwd(st.dh16, bk.xa, bk.mean1, bk.rstd1, bk.ln1_g, gmid, gout, st.gh16, M, Cs, nullptr, 0, nullptr, s, m->err_flag, st.LC);
 }
 
 int parse2(const char* name, const char* pfx, int* a, const char** rest) {
@@ -744,6 +902,7 @@ int vl_swin_create(const vl_swin_config* cfg, vl_swin** out) {
     vl_swin* m = new vl_swin();
     m->cfg = *cfg;
     m->f16 = cfg->reserved[0] == 1;
+    if (const char* up = getenv("VITLORA_SWIN_UNPAD")) m->unpad_stages = atoi(up);
     m->S = cfg->image_size; m->P = cfg->patch_size; m->G0 = m->S / m->P; m->E = cfg->embed_dim; m->C = cfg->num_labels;
     m->r = cfg->lora_targets ? cfg->lora_r : 0;
     m->scaling = m->r ? cfg->lora_alpha / (float)m->r : 0.f;
@@ -930,7 +1089,10 @@ static size_t swin_carve(vl_swin* m, int B, char* base) {
         if (m->f16) {
             const int64_t Rp = round_up((int64_t)B * st.H * st.H, 128);
             st.CP = padc(st.C); st.C3P = padc(3 * st.C); st.C4P = padc(4 * st.C);
-            auto th = [&](size_t n) { return (h16*)take(n * 2); };
+            const bool unpad = ((m->unpad_stages >> i) & 1) && st.C % 32 == 0;
+            st.LC = unpad ? st.C : st.CP; st.L3 = unpad ? 3 * st.C : st.C3P; st.L4 = unpad ? 4 * st.C : st.C4P;
+            // (+ 512 B: a GEMM whose A rows are narrower than its K reads that far past the last row)
+            auto th = [&](size_t n) { return (h16*)take(n * 2 + 512); };
             for (SBlock& bk : st.blocks) { bk.qkv16 = th((size_t)Rp * st.C3P); bk.z16 = th((size_t)Rp * st.C4P); }
             st.h16b = th((size_t)Rp * st.CP); st.a16 = th((size_t)Rp * st.C4P); st.delta16 = th((size_t)Rp * st.CP);
             st.ctx16 = th((size_t)Rp * st.CP); st.t16 = th((size_t)Rp * 64); st.u16 = th((size_t)Rp * 64);
@@ -1001,7 +1163,7 @@ static int swin_forward(vl_swin* m, const float* x, int B, int normalise, hipStr
                 swin16_block_fwd(m, st, st.blocks[bi], bi ? st.blocks[bi - 1].xb : nullptr, bi > 0, B, shift, s);
             }
             k_layernorm_fwd(st.blocks[st.depth - 1].xb, nullptr, nullptr, nullptr, nullptr, nullptr, M, Cs, m->cfg.ln_eps, st.delta16,
-                            i < 3 ? m->dbig : m->xlast, nullptr, 0, nullptr, s, st.CP);      // materialise the stage output (fp32)
+                            i < 3 ? m->dbig : m->xlast, nullptr, 0, nullptr, s, st.LC);      // materialise the stage output (fp32)
         }
         for (int bi = 0; bi < (m->f16 ? 0 : st.depth); ++bi) {
             SBlock& bk = st.blocks[bi];
@@ -1076,7 +1238,7 @@ static int swin_backward(vl_swin* m, float* grad_x, hipStream_t s) {
             hipLaunchKernelGGL(merge_gather_kernel, dim3(nblk((int64_t)M * Cs, 256, 8192)), dim3(256), 0, s, m->h, gcur, B, Hs, Hs, Cs, 1);
         }
         if (m->f16) {
-            k_pack_h16(gcur, st.gh16, M, Cs, st.CP, 0, 1.f, s);                         // h16 copy of the stage's output gradient
+            k_pack_h16(gcur, st.gh16, M, Cs, st.LC, 0, 1.f, s);                         // h16 copy of the stage's output gradient
             for (int bi = st.depth - 1; bi >= 0; --bi) {
                 const int shift = (bi & 1) && Hs > WS ? WS / 2 : 0;
                 swin16_block_bwd(m, st, st.blocks[bi], gcur, gnext, gcur, B, shift, s);
