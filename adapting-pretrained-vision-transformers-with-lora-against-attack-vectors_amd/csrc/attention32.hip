@@ -645,15 +645,25 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_fwd_img_kernel(const h16*
                     for (int r = 0; r < 16; ++r)
                         if (((NT - 1) * 32 + (r & 3) + 8 * (r >> 2)) >= tcut) S[NT - 1][r] = -INFINITY;
                 }
+                // T = 197 leaves 5 keys in the last tile: only its registers 0..3 (keys 0..3 / 4..7 of the tile) can be live, the
+                // other 12 are padding in every lane -- no maximum, no exp2, and no P V MFMA for the tile's upper 16 keys
+                const bool short_tail = (T & 31) != 0 && (T & 31) <= 8;
                 float tmax = -INFINITY;
 #pragma unroll
-                for (int kt = 0; kt < NT; ++kt)
+                for (int kt = 0; kt < NT - 1; ++kt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, S[kt][r]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, S[NT - 1][r]);
+                if (!short_tail) {
+#pragma unroll
+                    for (int r = 4; r < 16; ++r) tmax = fmaxf(tmax, S[NT - 1][r]);
+                }
                 m = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
                 const float mc = -m * scale_log2e;
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt) {
+                    if (kt == NT - 1 && short_tail) break;
                     // this tile's V fragments are requested before its exp2 block and consumed after it
                     h16x8 vfr[2][2];
 #pragma unroll
@@ -677,6 +687,17 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_fwd_img_kernel(const h16*
                         for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(vfr[st][dt], pb, o[dt]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                }
+                if (short_tail) {
+                    const h16x8 vt0 = tr_frag_o(sV, NT - 1, 0, fo.tr[0]), vt1 = tr_frag_o(sV, NT - 1, 0, fo.tr[1]);
+                    f32x16& Sl = S[NT - 1];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { Sl[r] = fexp2(fmaf(Sl[r], scale_log2e, mc)); l += Sl[r]; }
+#pragma unroll
+                    for (int r = 4; r < 16; ++r) Sl[r] = 0.f;
+                    const h16x8 pb = pack8(Sl, 0);
+                    o[0] = mfma32(vt0, pb, o[0]);
+                    o[1] = mfma32(vt1, pb, o[1]);
                 }
             } else {
                 f32x16 s_cur = scores(0);
@@ -1460,7 +1481,8 @@ int k_attention_img_fwd(const h16* qkv, h16* ctx, float* lse2, int B, int T, int
 }
 int k_attention_img_bwd(const h16* qkv, const h16* ctx, const h16* dctx, const float* lse2, h16* dqkv, int B, int T, int H, int D,
                         const h16* Bd, h16* u, int r, unsigned mods, hipStream_t s) {
-    ProfScope prof_("attn_bwd_img_kernel", 10.0 * B * H * (double)T * T * HD, (double)B * T * D * 16.0, s);
+    const bool ring = g_attn_ring && T <= (T <= 32 ? ring_img_rows<1>() : ring_img_rows<7>());      // the kernel launch_bwd_img picks
+    ProfScope prof_(ring ? "attn_bwd_ring_kernel" : "attn_bwd_img_kernel", 10.0 * B * H * (double)T * T * HD, (double)B * T * D * 16.0, s);
     LoraDown lo;
     lo.W = Bd; lo.out = u; lo.r = r; lo.mods = mods;
     if (!Bd || !u || r <= 0 || r > 8 || !mods) { lo.W = nullptr; lo.out = nullptr; }

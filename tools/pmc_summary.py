@@ -13,6 +13,7 @@ for name, counter, value, disp in c.execute("select kernel_name, counter_name, v
     k = name.replace("(anonymous namespace)::", "").replace("void ", "")
     k = re.sub(r"\(.*$", "", k)
     k = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", k)
+    k = re.sub(r"ILi(\d+)ELi(\d+)ELb(\d)EEEv.*$", r"<\1, \2, \3>", k)          # <int, int, bool>
     k = re.sub(r"ILi(\d+)EEEv.*$", r"<\1>", k)
     k = re.sub(r"ILi(\d+)ELi(\d+)EE.*$", r"<\1, \2>", k)
     k = re.sub(r"(_kernel)E[Pv].*$", r"\1", k)
