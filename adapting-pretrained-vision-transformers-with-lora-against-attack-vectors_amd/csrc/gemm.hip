@@ -20,6 +20,9 @@ int gemm256_init();
 void launch_gemm_pp(const GemmArgs& a, int epi, hipStream_t s);    // gemm_pp.hip
 bool gemm_pp_supports(const GemmArgs& a, int epi);
 int gemm_pp_init();
+void launch_gemm_stream(const GemmArgs& a, int epi, int bn, hipStream_t s);   // gemm_stream.hip
+bool gemm_stream_supports(const GemmArgs& a, int epi, int bn);
+int gemm_stream_init();
 
 namespace {
 
@@ -193,6 +196,7 @@ int gemm_init(int device) {
     set_attr<128, EPI_DROP_ACC>();
     if (int e2 = gemm256_init()) g_attr_err = e2;
     if (int e3 = gemm_pp_init()) g_attr_err = e3;
+    if (int e4 = gemm_stream_init()) g_attr_err = e4;
     const char* e = getenv("VITLORA_GEMM128");      // A/B switch: force the 128-row kernel
     g_force_small = (e && e[0] == '1') ? 1 : 0;
     const char* dp = getenv("VITLORA_DEPHASE");      // experiment knob: start-offset unit of gemm256
@@ -220,6 +224,10 @@ void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
         if (g_dephase >= 0) b.dephase = g_dephase;
         if (g_tile_group >= 0) b.tile_group = g_tile_group;
         launch_gemm256(b, epi, s);
+        return;
+    }
+    if (g_force_small != 1 && gemm_stream_supports(a, epi, bn)) {        // tall and shallow: an HBM stream (gemm_stream.hip)
+        launch_gemm_stream(a, epi, bn, s);
         return;
     }
     snprintf(name, sizeof name, "gemm_nt_kernel<128, %d, %d>", bn == 64 ? 64 : 128, epi);
