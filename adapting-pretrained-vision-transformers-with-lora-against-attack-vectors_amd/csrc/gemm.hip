@@ -214,6 +214,10 @@ void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
     const double mv = a.Mvalid ? a.Mvalid : a.M;
     const double flops = 2.0 * mv * (a.n_algo ? a.n_algo : a.N) * (a.K1 + (a.k2_algo ? a.k2_algo : a.K2));
     char name[64];
+    if (g_force_small != 1 && a.down_W && gemm_stream_fuses_down(a, epi)) {     // tall, shallow, LoRA down projection inside
+        launch_gemm_stream(a, epi, bn, s);
+        return;
+    }
     const bool narrow = a.n_store > 0 && a.n_store < a.N;      // only the 128-row kernel skips columns
     if (bn != 64 && g_force_small != 1 && !narrow && gemm_pp_supports(a, epi)) {
         launch_gemm_pp(a, epi, s);

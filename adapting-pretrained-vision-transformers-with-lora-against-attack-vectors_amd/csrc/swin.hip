@@ -795,11 +795,16 @@ void lin16_fwd(vl_swin* m, SStage& st, const SLin& ln, const h16* x, int ldx, in
     g.M = Mp; g.Mvalid = M; g.N = ln.outP; g.bias = ln.b16;
     g.n_store = g.ldc < ln.outP ? ln.out : 0;                      // unpadded result rows (ldc = out)
     if (ln.kext) {
-        GemmArgs d = ga(x, ldx, ln.Ad, ln.inP, ln.inP, Mp, 64);
-        d.Mvalid = M; d.C = st.t16; d.ldc = 64; d.n_algo = m->r * (int)ln.slots.size();
-        launch_gemm(d, EPI_STORE_H16, 64, s);
-        g.A2 = st.t16; g.lda2 = 64; g.W2 = ln.Bu; g.ldw2 = 64; g.K2 = 64;
+        g.W2 = ln.Bu; g.ldw2 = 64; g.K2 = 64;
         g.k2_algo = m->r; g.k2_used = m->r * (int)ln.slots.size();
+        g.down_W = ln.Ad; g.down_ldw = ln.inP; g.down_groups = 1;
+        if (!gemm_stream_fuses_down(g, epi)) {          // t = x Ad^T as its own skinny GEMM, read back as the LoRA K tile's A operand
+            g.down_W = nullptr; g.down_ldw = 0; g.down_groups = 0;
+            GemmArgs d = ga(x, ldx, ln.Ad, ln.inP, ln.inP, Mp, 64);
+            d.Mvalid = M; d.C = st.t16; d.ldc = 64; d.n_algo = m->r * (int)ln.slots.size();
+            launch_gemm(d, EPI_STORE_H16, 64, s);
+            g.A2 = st.t16; g.lda2 = 64;
+        }
     }
     launch_gemm(g, epi, 128, s);
 }
@@ -809,11 +814,16 @@ void lin16_dgrad(vl_swin* m, SStage& st, const SLin& ln, const h16* dy, int ldy,
     g.M = Mp; g.Mvalid = M; g.N = ln.inP; g.bias = nullptr;
     g.n_store = g.ldc < ln.inP ? ln.in : 0;
     if (ln.kext) {
-        GemmArgs d = ga(dy, ldy, ln.Bd, ln.outP, ln.outP, Mp, 64);
-        d.Mvalid = M; d.C = st.u16; d.ldc = 64; d.n_algo = m->r;
-        launch_gemm(d, EPI_STORE_H16, 64, s);
-        g.A2 = st.u16; g.lda2 = 64; g.W2 = ln.Au; g.ldw2 = 64; g.K2 = 64;
+        g.W2 = ln.Au; g.ldw2 = 64; g.K2 = 64;
         g.k2_algo = m->r * (int)ln.slots.size(); g.k2_used = g.k2_algo;
+        g.down_W = ln.Bd; g.down_ldw = ln.outP; g.down_groups = 1;
+        if (!gemm_stream_fuses_down(g, epi)) {
+            g.down_W = nullptr; g.down_ldw = 0; g.down_groups = 0;
+            GemmArgs d = ga(dy, ldy, ln.Bd, ln.outP, ln.outP, Mp, 64);
+            d.Mvalid = M; d.C = st.u16; d.ldc = 64; d.n_algo = m->r;
+            launch_gemm(d, EPI_STORE_H16, 64, s);
+            g.A2 = st.u16; g.lda2 = 64;
+        }
     }
     launch_gemm(g, epi, 128, s);
 }
