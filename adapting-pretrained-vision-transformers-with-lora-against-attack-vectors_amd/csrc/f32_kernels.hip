@@ -206,53 +206,57 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_big_kernel(const GemmF32 p) {
 constexpr int LNV = 8;       // float4 chunks per lane: rows up to 8 * 64 * 4 = 2048 features
 // LayerNorm (ViT eps 1e-12, configuration_vit.py:58; Swin 1e-5): one wave per row, D <= 2048
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ln_fwd_f32_kernel(const float* __restrict__ x, float* __restrict__ h,
-                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         int M, int D, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const float* xr = x + (int64_t)row * D;
-    const int nv = D >> 2;
-    f32x4_t v[LNV];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < LNV; ++i) {
-        const int c = lane + i * 64;
-        v[i] = c < nv ? *(const f32x4_t*)(xr + c * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-    }
-    const float mean = wave_sum(s) / D;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < LNV; ++i) {
-        const int c = lane + i * 64;
-        if (c < nv) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { const float d = v[i][k] - mean; q += d * d; }
-        }
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / D + eps);
-    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
-#pragma unroll
-    for (int i = 0; i < LNV; ++i) {
-        const int c = lane + i * 64;
-        if (c < nv) {
-            const f32x4_t g = *(const f32x4_t*)(gamma + c * 4), b = *(const f32x4_t*)(beta + c * 4);
-            f32x4_t o;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = (v[i][k] - mean) * rstd * g[k] + b[k];
-            *(f32x4_t*)(h + (int64_t)row * D + c * 4) = o;
-        }
-    }
-}
-
 template <int G>
 __device__ __forceinline__ float lane_group_sum(float v) {
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// NV float4 chunks per lane, G lanes per row (64 / G rows per wave), like ln_bwd_f32_kernel below: with one wave per row a
+// 96-wide row (Swin patch embedding) used 24 lanes of 64 and carried the registers of a 2048-wide one
+template <int NV, int G>
+__global__ __launch_bounds__(256) void ln_fwd_f32_kernel(const float* __restrict__ x, float* __restrict__ h,
+                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int M, int D, float eps) {
+    const int lane = threadIdx.x & 63, li = lane % G;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / G) + lane / G;
+    const bool live = row < M;
+    const int64_t off = (int64_t)(live ? row : M - 1) * D;
+    const int nv = D >> 2;
+    f32x4_t v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = li + i * G;
+        v[i] = c < nv ? *(const f32x4_t*)(x + off + c * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    const float mean = lane_group_sum<G>(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = li + i * G;
+        if (c < nv) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float d = v[i][k] - mean; q += d * d; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(lane_group_sum<G>(q) / D + eps);
+    if (!live) return;
+    if (li == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = li + i * G;
+        if (c < nv) {
+            const f32x4_t g = *(const f32x4_t*)(gamma + c * 4), b = *(const f32x4_t*)(beta + c * 4);
+            f32x4_t o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (v[i][k] - mean) * rstd * g[k] + b[k];
+            *(f32x4_t*)(h + off + c * 4) = o;
+        }
+    }
 }
 
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dh * gamma
@@ -810,7 +814,11 @@ void k_gemm_f32(const GemmF32& g, hipStream_t s) {
 }
 void k_ln_fwd_f32(const float* x, float* h, float* mean, float* rstd, const float* g, const float* b, int M, int D,
                   float eps, hipStream_t s) {
-    hipLaunchKernelGGL(ln_fwd_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, h, mean, rstd, g, b, M, D, eps);
+    const int nv = D / 4;
+#define LNF(NV_, G_) hipLaunchKernelGGL((ln_fwd_f32_kernel<NV_, G_>), dim3((M + 4 * (64 / G_) - 1) / (4 * (64 / G_))), dim3(256), 0, s, x, h, mean, rstd, g, b, M, D, eps)
+    if (nv <= 16) LNF(1, 16); else if (nv <= 32) LNF(1, 32); else if (nv <= 64) LNF(1, 64); else if (nv <= 128) LNF(2, 64);
+    else if (nv <= 256) LNF(4, 64); else LNF(8, 64);
+#undef LNF
 }
 void k_ln_bwd_f32(const float* dh, const float* x, const float* mean, const float* rstd, const float* g, const float* dres,
                   float* dx, int M, int D, hipStream_t s) {

@@ -306,6 +306,7 @@ __global__ __launch_bounds__(64 * (CW + 2)) void gemm_stream_kernel(const GemmAr
 int g_stream_cus = 0;
 int g_stream_on = 1;            // VITLORA_GEMM_STREAM=0: every such product on gemm_nt_kernel
 int g_stream_min_rows = 65536;  // tall ...
+int g_stream_min_rows64 = 8192;  // (the 64-column form: the LoRA down products that stay separate launches)
 int g_stream_max_k = 640;       // ... and shallow
 int g_stream_down = 1;          // VITLORA_GEMM_STREAM_DOWN=0: LoRA down projections stay separate launches
 
@@ -339,6 +340,7 @@ int gemm_stream_init() {
     g_stream_cus = cus;
     if (const char* e = getenv("VITLORA_GEMM_STREAM")) g_stream_on = e[0] != '0';
     if (const char* e = getenv("VITLORA_GEMM_STREAM_MIN_ROWS")) g_stream_min_rows = atoi(e);
+    if (const char* e = getenv("VITLORA_GEMM_STREAM_MIN_ROWS64")) g_stream_min_rows64 = atoi(e);
     if (const char* e = getenv("VITLORA_GEMM_STREAM_MAX_K")) g_stream_max_k = atoi(e);
     if (const char* e = getenv("VITLORA_GEMM_STREAM_DOWN")) g_stream_down = e[0] != '0';
     return g_stream_err;
@@ -355,8 +357,8 @@ bool gemm_stream_fuses_down(const GemmArgs& a, int epi) {
 bool gemm_stream_supports(const GemmArgs& a, int epi, int bn) {
     if (a.down_W) return gemm_stream_fuses_down(a, epi);
     if (!g_stream_on || a.a_gather) return false;
+    if (bn == 64) return a.M >= g_stream_min_rows64 && a.M % BM == 0 && a.K1 % BK == 0 && a.K2 == 0 && epi == EPI_STORE_H16 && a.N % 64 == 0;
     if (a.M < g_stream_min_rows || a.M % BM || a.K1 + a.K2 > g_stream_max_k || a.K1 % BK || a.K2 % BK) return false;
-    if (bn == 64) return epi == EPI_STORE_H16 && a.N % 64 == 0;
     if (a.N % 128) return false;
     return epi == EPI_STORE_H16 || epi == EPI_GELU || epi == EPI_GELU_BWD;
 }

@@ -25,6 +25,8 @@
 namespace {
 
 constexpr int WS = 7, WT = 49, HDIM = 32, KLD = 33;
+typedef _Float16 sh16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sh16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int win_row(int b, int w, int p, int H, int W, int shift) {
     const int nwx = W / WS;
@@ -207,6 +209,120 @@ __global__ void merge_gather_kernel(const float* __restrict__ x, float* __restri
         if (inverse) out[t] = x[o]; else out[o] = x[t];
     }
 }
+// 16-bit path: SwinPatchMerging's {2x2 gather, LayerNorm(4C)} in ONE pass over the stage output, which is read where it lies
+// (the fp32 stream xb of the stage's last block + that block's h16 MLP output `delta`, row stride ldd): no materialised stage
+// output, no gathered copy, no fp32 LayerNorm output, no pack pass -- the normalised rows leave as the h16 A operand of the
+// reduction GEMM.  Row r of the merged map = (b, y2, x2); its 4C features are C float4 chunks: chunk c belongs to quadrant
+// q = c / (C/4) = (x & 1) * 2 + (y & 1) (merge_gather_kernel's order).  NV chunks per lane, G lanes per row.
+template <int NV, int G>
+__global__ __launch_bounds__(256) void merge_ln_fwd16_kernel(const float* __restrict__ xb, const h16* __restrict__ delta, int ldd,
+                                                             h16* __restrict__ out, float* __restrict__ mean_out,
+                                                             float* __restrict__ rstd_out, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int B, int H, int W, int C, float eps) {
+    const int lane = threadIdx.x & 63, li = lane % G;
+    const int64_t Mq = (int64_t)B * (H / 2) * (W / 2);
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / G) + lane / G;
+    const bool live = row < Mq;
+    const int64_t r = live ? row : Mq - 1;
+    const int x2 = (int)(r % (W / 2)), y2 = (int)((r / (W / 2)) % (H / 2)), b = (int)(r / ((int64_t)(W / 2) * (H / 2)));
+    const int cq = C >> 2;                     // float4 chunks per quadrant
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = li + i * G, q = c / cq, ci = c - q * cq;
+        const int64_t src = ((int64_t)b * H + 2 * y2 + (q & 1)) * W + 2 * x2 + (q >> 1);
+        const f32x4 a = *(const f32x4*)(xb + src * C + ci * 4);
+        const sh16x4 d = *(const sh16x4*)(delta + src * ldd + ci * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[i][k] = a[k] + (float)d[k]; s += v[i][k]; }
+    }
+    const float D = 4.f * C;
+    float mean = s, qs = 0.f;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) mean += __shfl_xor(mean, o, 64);
+    mean /= D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float t = v[i][k] - mean; qs += t * t; }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) qs += __shfl_xor(qs, o, 64);
+    const float rstd = 1.0f / sqrtf(qs / D + eps);
+    if (!live) return;
+    if (li == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = li + i * G;
+        const f32x4 g = *(const f32x4*)(gamma + c * 4), bb = *(const f32x4*)(beta + c * 4);
+        sh16x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = f2h((v[i][k] - mean) * rstd * g[k] + bb[k]);
+        *(sh16x4*)(out + row * 4 * C + c * 4) = o;
+    }
+}
+// ... and its backward: dy [Mq, 4C] fp32 (the reduction's dgrad), x gathered again from xb + delta; the gradient w.r.t. the
+// stage output is scattered straight to its rows, as fp32 (residual-gradient stream) and h16 (row stride ldh)
+template <int NV, int G>
+__global__ __launch_bounds__(256) void merge_ln_bwd16_kernel(const float* __restrict__ dy, const float* __restrict__ xb,
+                                                             const h16* __restrict__ delta, int ldd, const float* __restrict__ mean_in,
+                                                             const float* __restrict__ rstd_in, const float* __restrict__ gamma,
+                                                             float* __restrict__ dx, h16* __restrict__ dx_h, int ldh, int B, int H, int W,
+                                                             int C, int* __restrict__ err) {
+    const int lane = threadIdx.x & 63, li = lane % G;
+    const int64_t Mq = (int64_t)B * (H / 2) * (W / 2);
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / G) + lane / G;
+    const bool live = row < Mq;
+    const int64_t r = live ? row : Mq - 1;
+    const int x2 = (int)(r % (W / 2)), y2 = (int)((r / (W / 2)) % (H / 2)), b = (int)(r / ((int64_t)(W / 2) * (H / 2)));
+    const int cq = C >> 2;
+    const float mean = mean_in[r], rstd = rstd_in[r];
+    f32x4 g[NV], xh[NV];
+    int64_t srow[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = li + i * G, q = c / cq, ci = c - q * cq;
+        srow[i] = (((int64_t)b * H + 2 * y2 + (q & 1)) * W + 2 * x2 + (q >> 1));
+        const f32x4 a = *(const f32x4*)(xb + srow[i] * C + ci * 4);
+        const sh16x4 d = *(const sh16x4*)(delta + srow[i] * ldd + ci * 4);
+        const f32x4 dv = *(const f32x4*)(dy + r * 4 * C + c * 4), gm = *(const f32x4*)(gamma + c * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            g[i][k] = dv[k] * gm[k];
+            xh[i][k] = (a[k] + (float)d[k] - mean) * rstd;
+            s1 += g[i][k];
+            s2 += g[i][k] * xh[i][k];
+        }
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    const float c1 = s1 / (4.f * C), c2 = s2 / (4.f * C);
+    if (!live) return;
+    bool sat = false;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = li + i * G, q = c / cq, ci = c - q * cq;
+        f32x4 o; sh16x4 ob;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[k] = rstd * (g[i][k] - c1 - xh[i][k] * c2);
+            ob[k] = f2h_sat(o[k]);
+            sat |= !(fabsf(o[k]) <= 65504.f);
+        }
+        *(f32x4*)(dx + srow[i] * C + ci * 4) = o;
+        *(sh16x4*)(dx_h + srow[i] * ldh + ci * 4) = ob;
+    }
+    if (sat && err) *err = 2;
+}
+// C = 96: 3 chunks x 32 lanes (two rows per wave); 192: 3 x 64; 384: 6 x 64
+template <class F> inline bool merge_dispatch(int C, F&& f) {
+    if (C == 96) { f(std::integral_constant<int, 3>{}, std::integral_constant<int, 32>{}); return true; }
+    if (C == 192) { f(std::integral_constant<int, 3>{}, std::integral_constant<int, 64>{}); return true; }
+    if (C == 384) { f(std::integral_constant<int, 6>{}, std::integral_constant<int, 64>{}); return true; }
+    return false;
+}
+
 // pooled[b][c] = mean over the L tokens of h[b][t][c]; inverse: dh[b][t][c] = dpooled[b][c] / L
 __global__ void mean_pool_kernel(const float* __restrict__ h, float* __restrict__ pooled, int B, int L, int C) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -257,8 +373,6 @@ __global__ void cls_bwd_kernel(const float* __restrict__ dlogits, const float* _
 // transpose read in the same k order ({4g.., 16 + 4g..}).
 // Per wave in LDS: Q, K, V (dO) row-major [64][32] h16, backward also P and dS as [q][key] images.
 // ===============================================================================================================
-typedef _Float16 sh16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 sh16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int W16T = 64;                 // padded tokens of a window
 // LDS layouts (bank-conflict free for every access kind below):
@@ -706,6 +820,7 @@ struct vl_swin {
     float *gscale = nullptr, *inv_gscale = nullptr, *dlogits_s = nullptr;
     int f16 = 0;             // cfg.reserved[0] == 1: 16-bit operand path for the blocks (embedding, merging and head stay fp32)
     int dirty = 1;           // packed h16 operands are stale (weights / adapters written since the last commit)
+    int fuse_merge = 1;      // VITLORA_SWIN_FUSE_MERGE=0: separate materialise / gather / LayerNorm / pack passes around the merges
     int unpad_stages = 1;    // bit i: stage i keeps its h16 activations at their true width (VITLORA_SWIN_UNPAD; default: stage 1 only)
 };
 
@@ -913,6 +1028,7 @@ int vl_swin_create(const vl_swin_config* cfg, vl_swin** out) {
     m->cfg = *cfg;
     m->f16 = cfg->reserved[0] == 1;
     if (const char* up = getenv("VITLORA_SWIN_UNPAD")) m->unpad_stages = atoi(up);
+    if (const char* fm = getenv("VITLORA_SWIN_FUSE_MERGE")) m->fuse_merge = fm[0] != '0';
     m->S = cfg->image_size; m->P = cfg->patch_size; m->G0 = m->S / m->P; m->E = cfg->embed_dim; m->C = cfg->num_labels;
     m->r = cfg->lora_targets ? cfg->lora_r : 0;
     m->scaling = m->r ? cfg->lora_alpha / (float)m->r : 0.f;
@@ -962,7 +1078,7 @@ int vl_swin_create(const vl_swin_config* cfg, vl_swin** out) {
         }
         if (i < 3) {
             A_(st.mg_g, 4 * Cs); A_(st.mg_b, 4 * Cs); A_(st.Wred, (size_t)2 * Cs * 4 * Cs); res /= 2;
-            if (m->f16) { A_(st.Wred16, (size_t)2 * Cs * 4 * Cs); A_(st.WredT16, (size_t)4 * Cs * 2 * Cs); }
+            if (m->f16) { A_(st.Wred16, (size_t)padc(2 * Cs) * 4 * Cs); A_(st.WredT16, (size_t)4 * Cs * 2 * Cs); }      // (rows 2C .. of Wred16 stay zero)
         }
     }
     const int Cl = m->E << 3;
@@ -1172,6 +1288,7 @@ static int swin_forward(vl_swin* m, const float* x, int B, int normalise, hipStr
                 const int shift = (bi & 1) && Hs > WS ? WS / 2 : 0;
                 swin16_block_fwd(m, st, st.blocks[bi], bi ? st.blocks[bi - 1].xb : nullptr, bi > 0, B, shift, s);
             }
+            if (i == 3 || !m->fuse_merge)
             k_layernorm_fwd(st.blocks[st.depth - 1].xb, nullptr, nullptr, nullptr, nullptr, nullptr, M, Cs, m->cfg.ln_eps, st.delta16,
                             i < 3 ? m->dbig : m->xlast, nullptr, 0, nullptr, s, st.LC);      // materialise the stage output (fp32)
         }
@@ -1189,6 +1306,20 @@ static int swin_forward(vl_swin* m, const float* x, int B, int normalise, hipStr
             k_gelu_fwd_f32(bk.z, m->a, (int64_t)M * 4 * Cs, s);
             lin_fwd(m, bk.fc2, m->a, M, xout, bk.xb, s);
         }
+        if (i < 3 && m->f16 && m->fuse_merge) {
+            // gather + LayerNorm(4C) in one pass over {xb, delta16}; the reduction (no bias) on h16 operands, its output rows
+            // narrower than the tile grid where 2C is not a multiple of 128 (stage 1: Wred16 carries zero rows up to 256)
+            const int Mq = (int)round_up(M / 4, 128), N2 = padc(2 * Cs);
+            merge_dispatch(Cs, [&](auto nv, auto gl) {
+                constexpr int NV = decltype(nv)::value, GL = decltype(gl)::value;
+                hipLaunchKernelGGL((merge_ln_fwd16_kernel<NV, GL>), dim3((M / 4 + 4 * (64 / GL) - 1) / (4 * (64 / GL))), dim3(256), 0, s,
+                                   st.blocks[st.depth - 1].xb, st.delta16, st.LC, st.mg16, st.mmean, st.mrstd, st.mg_g, st.mg_b, B, Hs, Hs,
+                                   Cs, m->cfg.ln_eps);
+            });
+            GemmArgs g16a = ga(st.mg16, 4 * Cs, st.Wred16, 4 * Cs, 4 * Cs, Mq, N2);
+            g16a.Mvalid = M / 4; g16a.C = m->stages[i + 1].blocks[0].xa; g16a.ldc = 2 * Cs; g16a.n_store = N2 > 2 * Cs ? 2 * Cs : 0;
+            launch_gemm(g16a, EPI_STORE_F32, 128, s);
+        } else
         if (i < 3) {        // SwinPatchMerging: 2x2 neighbourhood -> 4C, LayerNorm, Linear(4C -> 2C, no bias)
             hipLaunchKernelGGL(merge_gather_kernel, dim3(nblk((int64_t)M * Cs, 256, 8192)), dim3(256), 0, s, m->dbig, st.mg, B, Hs,
                                Hs, Cs, 0);
@@ -1244,10 +1375,21 @@ static int swin_backward(vl_swin* m, float* grad_x, hipStream_t s) {
                 launch_gemm(g16a, EPI_STORE_F32, 128, s);
             } else
             k_gemm_f32(gm(gcur, 2 * Cs, st.Wred, 4 * Cs, 1, M / 4, 4 * Cs, 2 * Cs, m->dbig, 4 * Cs), s);
+            if (m->f16 && m->fuse_merge) {
+                // LayerNorm(4C) backward with x gathered again from {xb, delta16}, un-merged on the way out: fp32 + h16 rows
+                merge_dispatch(Cs, [&](auto nv, auto gl) {
+                    constexpr int NV = decltype(nv)::value, GL = decltype(gl)::value;
+                    hipLaunchKernelGGL((merge_ln_bwd16_kernel<NV, GL>), dim3((M / 4 + 4 * (64 / GL) - 1) / (4 * (64 / GL))), dim3(256), 0, s,
+                                       m->dbig, st.blocks[st.depth - 1].xb, st.delta16, st.LC, st.mmean, st.mrstd, st.mg_g, gcur, st.gh16,
+                                       st.LC, B, Hs, Hs, Cs, m->err_flag);
+                });
+            } else {
             k_ln_bwd_f32(m->dbig, st.mg, st.mmean, st.mrstd, st.mg_g, nullptr, m->h, M / 4, 4 * Cs, s);
             hipLaunchKernelGGL(merge_gather_kernel, dim3(nblk((int64_t)M * Cs, 256, 8192)), dim3(256), 0, s, m->h, gcur, B, Hs, Hs, Cs, 1);
+            }
         }
         if (m->f16) {
+            if (i == 3 || !m->fuse_merge)
             k_pack_h16(gcur, st.gh16, M, Cs, st.LC, 0, 1.f, s);                         // h16 copy of the stage's output gradient
             for (int bi = st.depth - 1; bi >= 0; --bi) {
                 const int shift = (bi & 1) && Hs > WS ? WS / 2 : 0;
