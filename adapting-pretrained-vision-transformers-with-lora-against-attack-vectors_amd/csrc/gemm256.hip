@@ -82,10 +82,7 @@ __device__ __forceinline__ void glds4_sv(const void* sbase, unsigned voff, const
 // One launch walks `ntiles` BM-row tiles (row-major over (bm, bn), tile rows starting at bm0)
 // round-robin over the G workgroups.  A GEMM is one BM = 256 launch over full rounds plus, when
 // the tail pays, one BM = 128 launch over the remaining rows (plan_tiles below).
-// EXT = false: no second operand pair (K2 = 0) -- its lane offsets and operand selects are not compiled in (the GELU kernel
-// with them was three VGPRs over 256; the spilled values were reloaded inside K tile 0, and every scratch reload is an
-// s_waitcnt vmcnt(0): the previous tile's stores and all DMA in flight drained three times per output tile)
-template <int BM, int EPI, bool EXT = true>
+template <int BM, int EPI>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntiles, int bm0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     h16* sm = (h16*)smem;
@@ -101,7 +98,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
     const unsigned wl = PERM ? (unsigned)(16 * (lr >> 2) + (lr & 3)) : (unsigned)lr;   // lane part of the W row
     const int tilesN = p.N / BN;
     const int nk1 = p.K1 / BK;
-    const int nk = nk1 + (EXT ? p.K2 / BK : 0);
+    const int nk = nk1 + p.K2 / BK;
     const int G = gridDim.x, bid = (int)blockIdx.x;
 
     // ---- direct-to-LDS loaders ----------------------------------------------------------------
@@ -112,11 +109,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
     // addresses = wave-uniform base + 32-bit per-lane byte offset (operands are < 4 GiB);
     // nothing per-lane is kept between calls: row = uniform part + lr, 2 VALU per load.
     // per-lane byte offsets (kernel-invariant): row part (lr or the permuted W row) * ld + chunk
-    const unsigned voA1 = ((unsigned)lr * (unsigned)p.lda1 + csw) * 2u, voA2 = EXT ? ((unsigned)lr * (unsigned)p.lda2 + csw) * 2u : 0u;
-    const unsigned voW1 = (wl * (unsigned)p.ldw1 + csw) * 2u, voW2 = EXT ? (wl * (unsigned)p.ldw2 + csw) * 2u : 0u;
+    const unsigned voA1 = ((unsigned)lr * (unsigned)p.lda1 + csw) * 2u, voA2 = ((unsigned)lr * (unsigned)p.lda2 + csw) * 2u;
+    const unsigned voW1 = (wl * (unsigned)p.ldw1 + csw) * 2u, voW2 = (wl * (unsigned)p.ldw2 + csw) * 2u;
     auto issueA = [&](int bm, int h, int T) {
         constexpr int NA = BM / 128, BUF = (BM + BN) * BK;
-        const bool ext = EXT && T >= nk1;
+        const bool ext = T >= nk1;
         const char* Ap = (const char*)(ext ? p.A2 : p.A1);
         const unsigned lda = ext ? p.lda2 : p.lda1, k0 = (ext ? T - nk1 : T) * BK, vo = ext ? voA2 : voA1;
         h16* dst = sm + (T & 1) * BUF;
@@ -130,7 +127,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
     };
     auto issueW = [&](int bn, int h, int T) {
         constexpr int BUF = (BM + BN) * BK;
-        const bool ext = EXT && T >= nk1;
+        const bool ext = T >= nk1;
         const char* Wp = (const char*)(ext ? p.W2 : p.W1);
         const unsigned ldw = ext ? p.ldw2 : p.ldw1, k0 = (ext ? T - nk1 : T) * BK, vo = ext ? voW2 : voW1;
         h16* dst = sm + (T & 1) * BUF + BM * BK;
@@ -204,7 +201,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
             }
             __builtin_amdgcn_s_setprio(0);
         };
-        const bool ext_half = EXT && p.K2 == BK && p.k2_used > 0 && p.k2_used <= 32;   // the LoRA tile is the last K tile
+        const bool ext_half = p.K2 == BK && p.k2_used > 0 && p.k2_used <= 32;   // the LoRA tile is the last K tile
         // MODE 0: steady state (K tiles T+1 and T+2 exist); 1: T = nk-2; 2: T = nk-1
         // EXC: older in-flight epilogue instructions to tolerate (K tile 0 only)
         auto ktile = [&](int T, auto mode, auto extra) {
@@ -395,8 +392,7 @@ void launch_one(const GemmArgs& a, int ntiles, int bm0, hipStream_t s) {
                     gemm_algo_bytes(a, EPI, rows * valid), s);
     const int grid = ntiles < g_num_cus ? ntiles : g_num_cus;
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(h16) + 1024;
-    if (EPI == EPI_GELU && a.K2 == 0) hipLaunchKernelGGL((gemm256_kernel<BM, EPI, false>), dim3(grid), dim3(512), lds, s, a, ntiles, bm0);
-    else hipLaunchKernelGGL((gemm256_kernel<BM, EPI, true>), dim3(grid), dim3(512), lds, s, a, ntiles, bm0);
+    hipLaunchKernelGGL((gemm256_kernel<BM, EPI>), dim3(grid), dim3(512), lds, s, a, ntiles, bm0);
 }
 
 template <int EPI>
@@ -411,12 +407,8 @@ int g_attr_err256 = 0;
 template <int BM, int EPI>
 void set_attr1() {
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(h16) + 1024;
-    const hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<BM, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<BM, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) g_attr_err256 = (int)e;
-    if (EPI == EPI_GELU) {
-        const hipError_t e2 = hipFuncSetAttribute((const void*)gemm256_kernel<BM, EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e2 != hipSuccess) g_attr_err256 = (int)e2;
-    }
 }
 template <int EPI>
 void set_attr() { set_attr1<256, EPI>(); set_attr1<128, EPI>(); }
