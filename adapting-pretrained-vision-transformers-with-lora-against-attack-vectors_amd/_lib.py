@@ -64,6 +64,7 @@ SIGNATURES = {
     "vl_bench_gemm": (C.c_int, [C.c_int] * 7 + [C.POINTER(C.c_float)]),
     "vl_check_gemm": (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_float)]),
     "vl_debug_set_gemm_pp": (C.c_int, [C.c_int]),
+    "vl_debug_set_gemm_stream": (C.c_int, [C.c_int]),
     "vl_debug_set_cus": (C.c_int, [C.c_void_p, C.c_int]),
     "vl_check_errors": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vl_debug_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),

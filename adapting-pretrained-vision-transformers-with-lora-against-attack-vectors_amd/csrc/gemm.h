@@ -76,5 +76,6 @@ void gemm256_set_cus(int n);   // persistent grid size of the 256-row kernel (de
 void gemm_pp_set_cus(int n);
 int gemm_pp_mode();           // gemm_pp.hip: 0 = off, 1 = every supported shape, 2 = epilogue-heavy shapes only
 void gemm_pp_set_mode(int m);
+int gemm_stream_set_mode(int mode);    // bit 0: streaming kernel on, bit 1: LoRA down projection inside it; returns the old mode
 bool gemm_stream_fuses_down(const GemmArgs& a, int epi);   // gemm_stream.hip: a.down_W = [64 rows][K1] (down_ldw), W2 / K2 = 64 the LoRA K tile, A2 unused
 bool gemm_pp_fuses_down(const GemmArgs& a, int epi);   // a.down_* set: can launch_gemm run this GEMM with the down projection inside?   // per-device kernel attributes (outside any stream capture); 0 = ok

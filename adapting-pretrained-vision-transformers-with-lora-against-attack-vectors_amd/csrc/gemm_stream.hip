@@ -346,6 +346,12 @@ int gemm_stream_init() {
     return g_stream_err;
 }
 
+int gemm_stream_set_mode(int mode) {
+    const int old = (g_stream_on ? 1 : 0) | (g_stream_down ? 2 : 0);
+    g_stream_on = mode & 1; g_stream_down = (mode >> 1) & 1;
+    return old;
+}
+
 // bn: 128 or 64 (the caller's column tile, as for gemm_nt_kernel)
 // a.down_W set (down_groups = 1: 64 rows, down_ldw), W2 / ldw2 / K2 = 64 the LoRA K tile, A2 unused: can the down projection
 // run inside this GEMM?
@@ -367,7 +373,7 @@ void launch_gemm_stream(const GemmArgs& a, int epi, int bn, hipStream_t s) {
     const double mv = a.Mvalid ? a.Mvalid : a.M;
     const double flops = 2.0 * mv * (a.n_algo ? a.n_algo : a.N) * (a.K1 + (a.k2_algo ? a.k2_algo : a.K2));
     char name[64];
-    snprintf(name, sizeof name, "gemm_stream_kernel<%d, %d>", bn == 64 ? 64 : 128, epi);
+    snprintf(name, sizeof name, "gemm_stream_kernel<%d, %d, %s>", bn == 64 ? 64 : 128, epi, a.down_W ? "true" : "false");    // as rocprofv3 prints it
     ProfScope prof_(name, flops, gemm_algo_bytes(a, epi, mv), s);
     if (a.down_W) {
         if (epi == EPI_STORE_H16) launch_s<128, EPI_STORE_H16, true>(a, s);

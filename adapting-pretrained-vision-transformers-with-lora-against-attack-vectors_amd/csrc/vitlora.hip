@@ -1230,6 +1230,7 @@ int vl_debug_set_option(vl_model* m, const char* name, int value) {
 }
 
 int vl_debug_set_gemm_pp(int mode) { const int old = gemm_pp_mode(); gemm_pp_set_mode(mode); return old; }
+int vl_debug_set_gemm_stream(int mode) { return gemm_stream_set_mode(mode); }
 
 // ---- profiling -------------------------------------------------------------------------------
 int vl_profile_begin(void) {

@@ -260,6 +260,10 @@ int vl_bench_gemm(int M, int N, int K1, int K2, int epi, int bn, int iters, floa
 int vl_check_gemm(int M, int N, int K1, int K2, int epi, int pp_mode, float* max_diff);
 /* A/B switch of the ping-pong GEMM (same values as the environment variable VITLORA_GEMM_PP); returns the old mode. */
 int vl_debug_set_gemm_pp(int mode);
+/* A/B switch of the streaming GEMM (tall, shallow products: the Swin stages 1-2; csrc/gemm_stream.hip): bit 0 = kernel on,
+ * bit 1 = LoRA down projections computed inside it (same values as VITLORA_GEMM_STREAM / VITLORA_GEMM_STREAM_DOWN);
+ * returns the old mode. */
+int vl_debug_set_gemm_stream(int mode);
 /* Diagnostic switches of one handle: "dead_rows" (1: eval-mode forwards compute the last encoder layer on the CLS rows only,
  * exact; 0: every row) and "fuse_pgd" (1: vl_pgd_attack applies K10 in the patch-gradient epilogue; 0: separate launch). */
 int vl_debug_set_option(vl_model* m, const char* name, int value);

@@ -162,6 +162,38 @@ def test_swin_t_batch256_pgd_properties_and_shard_invariance(prec):
     assert torch.equal(part, full[64:128]), (part - full[64:128]).abs().max().item()
 
 
+def test_swin_streaming_gemm_and_fused_lora_down_reproduce_the_tile_kernel():
+    """The tall, shallow products of Swin stages 1-2 (M = batch x 3136 rows >= 65536 from batch 21 on) run on the streaming
+    GEMM (csrc/gemm_stream.hip), with the LoRA down projection computed inside it.  Same MFMA, same K order, the same single
+    rounding of t: logits and input gradient must equal those of the independent-tile kernel + separate skinny GEMMs
+    (vl_debug_set_gemm_stream 0) to the last bit, and the mode without the fused down projection likewise."""
+    import test_hip_swin as TS
+    lib = importlib.import_module(PKG + "._lib").load()
+    m = TS.hf_swin(21, seed=31)
+    ab = TS.add_lora(m, 16, 16.0, seed=33)
+    g = torch.Generator().manual_seed(35)
+    x = torch.rand(32, 3, 224, 224, generator=g).cuda()
+    y = torch.randint(0, 21, (32,), generator=g).cuda()
+    outs = {}
+    old = lib.vl_debug_set_gemm_stream(3)
+    try:
+        for mode in (3, 1, 0):
+            lib.vl_debug_set_gemm_stream(mode)
+            eng = TS.make_engine(m, 21, 16, ab, precision="f16")
+            logits = eng.forward(x, normalise=True).clone()
+            eng.loss_ce(y)
+            gx = eng.backward_input(tuple(x.shape)).clone()
+            torch.cuda.synchronize()
+            outs[mode] = (logits, gx)
+            del eng
+    finally:
+        lib.vl_debug_set_gemm_stream(old)
+    for mode in (3, 1):
+        assert torch.equal(outs[mode][0], outs[0][0]), (mode, (outs[mode][0] - outs[0][0]).abs().max().item())
+        assert torch.equal(outs[mode][1], outs[0][1]), (mode, (outs[mode][1] - outs[0][1]).abs().max().item())
+    assert outs[0][1].abs().max().item() > 0
+
+
 # ---- BASELINE config 5 at full size: ViT-L/16 + LoRA r = 16, adversarial patch EoT step, batch 128 --------------------
 
 def test_vit_l16_batch128_patch_eot_step_properties_and_gradient_exchange():
