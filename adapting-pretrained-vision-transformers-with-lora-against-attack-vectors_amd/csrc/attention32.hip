@@ -29,6 +29,13 @@ __device__ unsigned long long g_attn_stamps[8192 * 8 * 8];
 #define STAMP(k) do { } while (0)
 #define ISTAMP(hd, k) do { } while (0)
 #endif
+#ifdef VITLORA_ATTN_STAMPS_FWD   // per-head stamps of the per-image forward (tools/attn_fwd_stamp.hip); the backward's are off
+#undef ISTAMP
+#define ISTAMP(hd, k) do { } while (0)
+#define FSTAMP(hd, k) do { if ((hd) == 3) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); if (blockIdx.x < 1024 && (threadIdx.x & 63) == 0) g_attn_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = t_; } } while (0)
+#else
+#define FSTAMP(hd, k) do { } while (0)
+#endif
 #ifdef VITLORA_ATTN_STAMPS2   // intra-step stamps of the ring backward (step 3 of head 3), instead of the per-head ones
 #undef ISTAMP
 #define ISTAMP(hd, k) do { } while (0)
@@ -554,6 +561,7 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_fwd_img_kernel(const h16*
     for (int hd = 0; hd < H; ++hd) {
         const h16* sK = ring + (hd & 1) * 2 * ROWS * HD;
         const h16* sV = sK + ROWS * HD;
+        FSTAMP(hd, 0);
         if (loader) {
             if (hd + 1 < H) {
                 h16* nK = ring + ((hd + 1) & 1) * 2 * ROWS * HD;
@@ -562,6 +570,7 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_fwd_img_kernel(const h16*
                 if (lo.W) stage_down(sAd + ((hd + 1) & 1) * 8 * HD, lo.W, D, 0, lo.r, (hd + 1) * HD, lane);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FSTAMP(hd, 5);
         } else if (active) {
             float m = -INFINITY, l = 0.f;
             f32x16 o[2];
@@ -640,6 +649,7 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_fwd_img_kernel(const h16*
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+                FSTAMP(hd, 1);
                 if (T & 31) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -661,6 +671,7 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_fwd_img_kernel(const h16*
                 }
                 m = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
                 const float mc = -m * scale_log2e;
+                FSTAMP(hd, 2);
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt) {
                     if (kt == NT - 1 && short_tail) break;
@@ -710,6 +721,7 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_fwd_img_kernel(const h16*
                 }
                 if (T & 31) step(nfull, s_cur, std::true_type{});
             }
+            FSTAMP(hd, 3);
             if (hd + 1 < H) {                                  // next head's query fragments fly under the epilogue
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const h16x8*)(base + (size_t)qc * ld + (hd + 1) * HD + 8 * h + 16 * ks);
@@ -735,8 +747,11 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_fwd_img_kernel(const h16*
                 store_rows32_half(wimg + w * 2048, o, inv, ctx + (size_t)b * T * D + hd * HD, D, w * 32, T, lane);
             }
             if (q < T && h == 0) lse2[((size_t)b * H + hd) * T + q] = m * scale_log2e + log2f(l);
+            FSTAMP(hd, 4);
         }
+        FSTAMP(hd, 6);
         LDS_BARRIER();
+        FSTAMP(hd, 7);
     }
     if (lo.W && !loader && active && q < T && 4 * h < lo.r) {
         const f32x4 t4 = *(const f32x4*)(tsum + q * 8 + 4 * h);      // LoRA columns 4h .. 4h+3 of this token

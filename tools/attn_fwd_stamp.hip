@@ -1,0 +1,51 @@
+// Diagnostic: where a head of the per-image attention forward spends its cycles (head 3 of every workgroup).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DVITLORA_ATTN_STAMPS -DVITLORA_ATTN_STAMPS_FWD -I<csrc> tools/attn_fwd_stamp.hip -o tools/attn_fwd_stamp
+// stamps: 0 head start | 1 after the 28 score MFMAs | 2 after the row maximum | 3 after exp2 + P V | 4 after the LoRA down product and the
+//         stores | 5 (loader) next head's K / V landed | 6 before the end-of-head barrier | 7 after it
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "attention32.hip"
+Profiler* g_prof = nullptr;
+int main(int argc, char** argv) {
+    const int B = 256, T = 197, H = 12, D = 768;
+    const bool with_lora = argc > 1;
+    const size_t nq = (size_t)B * T * 3 * D, nc = (size_t)B * T * D;
+    std::vector<unsigned short> hq(nq);
+    srand(1);
+    auto rnd = [] { _Float16 f = (_Float16)(rand() / (float)RAND_MAX - 0.5f); unsigned short u; memcpy(&u, &f, 2); return u; };
+    for (auto& v : hq) v = rnd();
+    h16 *qkv, *ctx, *Ad, *t; float* lse;
+    hipMalloc(&qkv, nq * 2); hipMalloc(&ctx, nc * 2); hipMalloc(&lse, (size_t)B * H * T * 4);
+    hipMalloc(&Ad, 64 * D * 2); hipMalloc(&t, (size_t)B * T * 64 * 2 + 4096);
+    hipMemcpy(qkv, hq.data(), nq * 2, hipMemcpyHostToDevice); hipMemcpy(Ad, hq.data(), 64 * D * 2, hipMemcpyHostToDevice);
+    attention32_init(0);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms;
+    for (int i = 0; i < 3; ++i) k_attention_img_fwd(qkv, ctx, lse, B, T, H, D, with_lora ? Ad : nullptr, t, with_lora ? 8 : 0, 0);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < 5; ++i) k_attention_img_fwd(qkv, ctx, lse, B, T, H, D, with_lora ? Ad : nullptr, t, with_lora ? 8 : 0, 0);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("forward: %.1f us per launch (batch %d, lora %d)\n", ms * 1e3 / 5, B, (int)with_lora);
+    std::vector<unsigned long long> st(8192 * 8 * 8);
+    hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_attn_stamps), st.size() * 8);
+    const char* names[] = {"head 0->7", "scores (0->1)", "row max (1->2)", "exp2 + PV (2->3)", "down + stores (3->4)", "wait (4->6)", "barrier (6->7)", "loader load (0->5)"};
+    const int a[] = {0, 0, 1, 2, 3, 4, 6, 0}, b2[] = {7, 1, 2, 3, 4, 6, 7, 5};
+    for (int wv = 0; wv < 8; ++wv) {
+        printf("wave %d:", wv);
+        for (int k = 0; k < 8; ++k) {
+            double sum = 0; int n = 0;
+            for (int blk = 0; blk < B; ++blk) {
+                const unsigned long long* s = &st[(blk * 8 + wv) * 8];
+                if (s[b2[k]] > s[a[k]] && s[a[k]]) { sum += (double)(s[b2[k]] - s[a[k]]); ++n; }
+            }
+            if (n) printf("  %s %.0f", names[k], sum / n);
+        }
+        printf("\n");
+    }
+    return 0;
+}
