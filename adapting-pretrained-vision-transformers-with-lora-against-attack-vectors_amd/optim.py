@@ -28,8 +28,11 @@ def allreduce_weighted_mean_(flat_grad: torch.Tensor, local_count, global_count,
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         if local_count is not None and global_count:
-            flat_grad.mul_(float(local_count) * dist.get_world_size(group) / float(global_count))
-        allreduce_mean_(flat_grad, group)
+            # ONE scale (n_r / n) and ONE collective (SUM) on the single flat buffer: the flat-gradient exchange of SURVEY 8e
+            flat_grad.mul_(float(local_count) / float(global_count))
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+        else:
+            allreduce_mean_(flat_grad, group)
     return flat_grad
 
 
@@ -106,7 +109,7 @@ class Adam:
         else:
             g = p.grad.contiguous()
         if use_dist:
-            g = g.clone() if p.grad is not None else g
+            # (in place: p.grad is the library's flat gradient buffer, rewritten by the next backward)
             allreduce_weighted_mean_(g, local_count, global_count, self.group)
         vit, eng = self._engine()
         self.t += 1
