@@ -111,6 +111,30 @@ def extras(P, syn, arch, args, dev, x, y):
         train_step(t)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
+
+    # BASELINE config 3 itself: the adversarial example is made INSIDE the step, against the current adapters (PGD-7, the
+    # inner loop of train_loras.py --pgd-inner-steps), then the train step runs on it -- 64 images per GPU
+    def adv_train_step(t):
+        xa = eng.pgd_attack(xt, yt, EPS, ALPHA, 7, True, seed=t)
+        eng.forward(xa, normalise=True, train=True)
+        eng.loss_ce(yt)
+        _, g = eng.backward(False, True)
+        eng.adam_step(eng.flat, g, m1, m2, 1e-4, 0.9, 0.999, 1e-8, t)
+        eng.commit()
+
+    for t in range(20, 22):
+        adv_train_step(t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    na = 5
+    for t in range(22, 22 + na):
+        adv_train_step(t)
+    torch.cuda.synchronize()
+    dta = (time.perf_counter() - t0) / na
+    res["adv_lora_train_step_pgd7"] = {"value": bt / dta, "unit": "img/s", "ms_per_step": 1e3 * dta, "batch": bt,
+                                       "what": "PGD-7 against the current adapters + forward(train, dropout 0.1) + CE + LoRA/classifier "
+                                               "backward + Adam (BASELINE config 3, one GPU's 64 images)"}
+    log(f"extras: adversarial LoRA train step (PGD-7 inner) {1e3 * dta:.2f} ms at batch {bt}")
     if args.vitl:
         # BASELINE config 5's model family (ViT-L/16 + LoRA r = 16, 128 images per GPU): the same PGD attack
         del eng
