@@ -149,22 +149,24 @@ __global__ __launch_bounds__(256) void attn_cls_bwd_kernel(const h16* __restrict
 }
 
 // dst[b][0..D) = src[b * stride .. + D)   (fp32, D % 4 == 0)
-__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int D,
+__global__ __launch_bounds__(256) void gather_rows_kernel(const h16* __restrict__ src, float* __restrict__ dst, int B, int D,
                                                           int64_t stride) {
     const int n4 = D / 4;
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * n4) return;
     const int b = (int)(i / n4), c = (int)(i - (int64_t)b * n4);
-    *(f32x4*)(dst + (int64_t)b * D + 4 * c) = *(const f32x4*)(src + b * stride + 4 * c);
+    const h16x4 v = *(const h16x4*)(src + b * stride + 4 * c);
+    *(f32x4*)(dst + (int64_t)b * D + 4 * c) = f32x4{h2f(v[0]), h2f(v[1]), h2f(v[2]), h2f(v[3])};
 }
 // dst[b * stride .. + D) = src[b][0..D)
-__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int D,
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ src, h16* __restrict__ dst, int B, int D,
                                                            int64_t stride) {
     const int n4 = D / 4;
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * n4) return;
     const int b = (int)(i / n4), c = (int)(i - (int64_t)b * n4);
-    *(f32x4*)(dst + b * stride + 4 * c) = *(const f32x4*)(src + (int64_t)b * D + 4 * c);
+    const f32x4 v = *(const f32x4*)(src + (int64_t)b * D + 4 * c);
+    *(h16x4*)(dst + b * stride + 4 * c) = h16x4{f2h_sat(v[0]), f2h_sat(v[1]), f2h_sat(v[2]), f2h_sat(v[3])};
 }
 
 }  // namespace
@@ -184,11 +186,11 @@ int k_attn_cls_bwd(const h16* qkv, const h16* ctx_c, const h16* dctx_c, const fl
                        0.125f, 0.125f * 1.4426950408889634f);
     return 0;
 }
-void k_gather_rows(const float* src, float* dst, int B, int D, int64_t stride, hipStream_t s) {
+void k_gather_rows(const h16* src, float* dst, int B, int D, int64_t stride, hipStream_t s) {
     const int64_t n = (int64_t)B * (D / 4);
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, B, D, stride);
 }
-void k_scatter_rows(const float* src, float* dst, int B, int D, int64_t stride, hipStream_t s) {
+void k_scatter_rows(const float* src, h16* dst, int B, int D, int64_t stride, hipStream_t s) {
     const int64_t n = (int64_t)B * (D / 4);
     hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, B, D, stride);
 }

@@ -37,12 +37,13 @@ __global__ void patch_gather_kernel(const float* __restrict__ x, h16* __restrict
 }
 
 // x[b*T + 0][:] = cls + pos[0]   (ViTEmbeddings: cat(cls, patches) + position_embeddings)
-__global__ void cls_rows_kernel(float* __restrict__ x, const float* __restrict__ cls,
+template <typename XT>
+__global__ void cls_rows_kernel(XT* __restrict__ x, const float* __restrict__ cls,
                                 const float* __restrict__ pos, int B, int T, int D) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * D) return;
     const int b = i / D, d = i - b * D;
-    x[(int64_t)b * T * D + d] = cls[d] + pos[d];
+    x[(int64_t)b * T * D + d] = (XT)(cls[d] + pos[d]);
 }
 
 // ---------------------------------------------------------------------------------
@@ -332,6 +333,222 @@ __global__ __launch_bounds__(256) void layernorm_bwd_small_kernel(const h16* __r
 }
 
 // ---------------------------------------------------------------------------------
+// 16-bit residual streams (round 4; the ViT path's 16-bit precision).  The residual stream x and the residual-gradient
+// stream are stored as h16 -- HF runs this model with an fp16 residual stream -- so a LayerNorm pass moves 8 B per
+// element instead of 12 (forward) / 16 (backward): forward reads x, delta and writes x' = round16(x + delta) and h;
+// backward reads dh, x', the incoming stream gradient and writes the outgoing one IN PLACE, which is also the A operand
+// of the next dgrad GEMM (the fp32 stream had a separate h16 shadow for that).  Statistics and all arithmetic stay fp32;
+// the forward normalises the ROUNDED x', so the backward (which re-derives xhat from the saved x') differentiates exactly
+// the function the forward computed.  tools/error_budget_streams.py prices the two roundings on ViT-B: logits 6.7e-4 ->
+// 1.0e-3, input gradient 1.4e-3 -> 1.7e-3 against the fp32 reference (north_star: 1e-2).
+// Layout: 32 lanes per row (two rows per wave), 16-byte chunk c = li + 32 i of the row per lane: every access is a
+// global_load/store_dwordx4 (8-byte accesses reach 0.54-0.70 of that rate, MI355X_MICROARCH.md).
+// Fused LoRA down projection (NG > 0): out[j] = sum_k v[k] P[j][k] for the 8 NG rows of P, P staged ONCE per workgroup in
+// LDS (in registers it would cost this layout 96 VGPRs per group), blocks walk the rows grid-stride.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float dot8(h16x8 a, h16x8 b, float acc) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const h2 x = {a[2 * k], a[2 * k + 1]}, y = {b[2 * k], b[2 * k + 1]};
+        acc = __builtin_amdgcn_fdot2(x, y, acc, false);
+    }
+    return acc;
+}
+template <int NV, int NG>
+__device__ __forceinline__ void lora_down_row16(const h16x8 (&v)[NV], const h16* sP, int D, int nc, int li, int half,
+                                                h16* __restrict__ out_row, bool live) {
+    float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = li + i * 32;
+            if (c < nc) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = dot8(v[i], *(const h16x8*)(sP + (size_t)(gq * 8 + j) * D + c * 8), acc[j]);
+            }
+        }
+        // halving butterfly inside the half wave: 4 + 2 + 1 exchanges leave lane li with column (li >> 2) & 7, two xor steps finish
+        const bool b4 = li & 16, b3 = li & 8, b2 = li & 4;
+        float a4[4], a2[2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a4[q] = (b4 ? acc[4 + q] : acc[q]) + __shfl_xor(b4 ? acc[q] : acc[4 + q], 16, 64);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a2[q] = (b3 ? a4[2 + q] : a4[q]) + __shfl_xor(b3 ? a4[q] : a4[2 + q], 8, 64);
+        float a1 = (b2 ? a2[1] : a2[0]) + __shfl_xor(b2 ? a2[0] : a2[1], 4, 64);
+        a1 += __shfl_xor(a1, 2, 64);
+        a1 += __shfl_xor(a1, 1, 64);
+        // lane li stores columns 2 li, 2 li + 1 of the 64-column row: group li >> 2, columns 2 (li & 3) and the next one
+        const int src = half * 32 + ((li & 3) << 3);
+        const float v0 = __shfl(a1, src, 64), v1 = __shfl(a1, src + 4, 64);
+        if ((li >> 2) == gq) { o0 = v0; o1 = v1; }
+    }
+    if (live) *(h16x2*)(out_row + 2 * li) = h16x2{f2h(o0), f2h(o1)};
+}
+
+template <int NV, int NG>
+__global__ __launch_bounds__(256) void layernorm_fwd16_kernel(const h16* __restrict__ x, h16* __restrict__ h,
+                                                              float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              int M, int D, float eps, const h16* __restrict__ delta,
+                                                              h16* __restrict__ xout, const h16* __restrict__ P,
+                                                              h16* __restrict__ t, int* __restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) char ln_smem[];
+    h16* sP = (h16*)ln_smem;
+    const int lane = threadIdx.x & 63, li = lane & 31, half = lane >> 5;
+    const int nc = D >> 3;
+    if constexpr (NG > 0) {
+        for (int i = threadIdx.x; i < 8 * NG * nc; i += 256) ((h16x8*)sP)[i] = ((const h16x8*)P)[i];
+        __syncthreads();
+    }
+    bool sat = false;
+    const int pairs = (M + 1) >> 1;
+    for (int pr = blockIdx.x * 4 + (threadIdx.x >> 6); pr < pairs; pr += gridDim.x * 4) {
+        const int row = pr * 2 + half;
+        const bool live = row < M;
+        const int64_t off = (int64_t)(live ? row : M - 1) * D;
+        f32x4 v[NV][2];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = li + i * 32;
+            v[i][0] = v[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < nc) {
+                const h16x8 xv = *(const h16x8*)(x + off + c * 8);
+                if (delta) {
+                    // residual add fused in: x' = round16(x + delta) (delta = the h16 output of the projection before it)
+                    const h16x8 dl = *(const h16x8*)(delta + off + c * 8);
+                    h16x8 xr;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float a = h2f(xv[k]) + h2f(dl[k]);
+                        sat |= !(fabsf(a) <= 65504.f);
+                        xr[k] = f2h(a);
+                        v[i][k >> 2][k & 3] = h2f(xr[k]);
+                    }
+                    if (live) *(h16x8*)(xout + off + c * 8) = xr;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[i][k >> 2][k & 3] = h2f(xv[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s += v[i][0][k] + v[i][1][k];
+            }
+        }
+        if (!h) continue;                            // add only (the head normalises the CLS rows)
+        const float mean = half_wave_sum(s) / D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (li + i * 32 < nc) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float d0 = v[i][0][k] - mean, d1 = v[i][1][k] - mean;
+                    q += d0 * d0 + d1 * d1;
+                }
+            }
+        }
+        const float rstd = rsqrtf(half_wave_sum(q) / D + eps);
+        if (li == 0 && live) { mean_out[row] = mean; rstd_out[row] = rstd; }
+        h16x8 vb[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = li + i * 32;
+            vb[i] = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (c < nc) {
+                const f32x4 g0 = *(const f32x4*)(gamma + c * 8), g1 = *(const f32x4*)(gamma + c * 8 + 4);
+                const f32x4 b0 = *(const f32x4*)(beta + c * 8), b1 = *(const f32x4*)(beta + c * 8 + 4);
+                h16x8 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    o[k] = f2h((v[i][0][k] - mean) * rstd * g0[k] + b0[k]);
+                    o[4 + k] = f2h((v[i][1][k] - mean) * rstd * g1[k] + b1[k]);
+                }
+                if (live) *(h16x8*)(h + off + c * 8) = o;
+                vb[i] = o;
+            }
+        }
+        if constexpr (NG > 0) lora_down_row16<NV, NG>(vb, sP, D, nc, li, half, t + (int64_t)(live ? row : 0) * 64, live);
+    }
+    if (sat && err) *err = 2;
+}
+
+// dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dh * gamma, xhat = (x - mean) * rstd; `dres` is read and
+// overwritten in place (each row by the half wave that read it)
+template <int NV, int NG>
+__global__ __launch_bounds__(256) void layernorm_bwd16_kernel(const h16* __restrict__ dh, const h16* __restrict__ x,
+                                                              const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                              const float* __restrict__ gamma, h16* dres, int M, int D,
+                                                              const h16* __restrict__ P, h16* __restrict__ u, int* __restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) char ln_smem[];
+    h16* sP = (h16*)ln_smem;
+    const int lane = threadIdx.x & 63, li = lane & 31, half = lane >> 5;
+    const int nc = D >> 3;
+    if constexpr (NG > 0) {
+        for (int i = threadIdx.x; i < 8 * NG * nc; i += 256) ((h16x8*)sP)[i] = ((const h16x8*)P)[i];
+        __syncthreads();
+    }
+    bool sat = false;          // a gradient that left the fp16 range (clamped by f2h_sat below) or is NaN: reported, never silent
+    const int pairs = (M + 1) >> 1;
+    for (int pr = blockIdx.x * 4 + (threadIdx.x >> 6); pr < pairs; pr += gridDim.x * 4) {
+        const int row = pr * 2 + half;
+        const bool live = row < M;
+        const int rr = live ? row : M - 1;
+        const int64_t off = (int64_t)rr * D;
+        const float mean = mean_in[rr], rstd = rstd_in[rr];
+        h16x8 rv[NV];
+        f32x4 g[NV][2], xh[NV][2];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = li + i * 32;
+            g[i][0] = g[i][1] = xh[i][0] = xh[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            rv[i] = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (c < nc) {
+                const h16x8 d = *(const h16x8*)(dh + off + c * 8);
+                const h16x8 xv = *(const h16x8*)(x + off + c * 8);
+                rv[i] = *(const h16x8*)(dres + off + c * 8);
+                const f32x4 g0 = *(const f32x4*)(gamma + c * 8), g1 = *(const f32x4*)(gamma + c * 8 + 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    g[i][0][k] = h2f(d[k]) * g0[k];
+                    g[i][1][k] = h2f(d[4 + k]) * g1[k];
+                    xh[i][0][k] = (h2f(xv[k]) - mean) * rstd;
+                    xh[i][1][k] = (h2f(xv[4 + k]) - mean) * rstd;
+                    s1 += g[i][0][k] + g[i][1][k];
+                    s2 += g[i][0][k] * xh[i][0][k] + g[i][1][k] * xh[i][1][k];
+                }
+            }
+        }
+        const float c1 = half_wave_sum(s1) / D, c2 = half_wave_sum(s2) / D;
+        h16x8 vb[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = li + i * 32;
+            vb[i] = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (c < nc) {
+                h16x8 ob;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float o = h2f(rv[i][k]) + rstd * (g[i][k >> 2][k & 3] - c1 - xh[i][k >> 2][k & 3] * c2);
+                    ob[k] = f2h_sat(o);
+                    sat |= !(fabsf(o) <= 65504.f);
+                }
+                if (live) *(h16x8*)(dres + off + c * 8) = ob;
+                vb[i] = ob;                                              // the row as the next dgrad GEMM reads it
+            }
+        }
+        // u = dx B of the projection whose dgrad consumes dx next (linear_dgrad skips its down GEMM)
+        if constexpr (NG > 0) lora_down_row16<NV, NG>(vb, sP, D, nc, li, half, u + (int64_t)rr * 64, live);
+    }
+    if (sat && err) *err = 2;
+}
+
+// ---------------------------------------------------------------------------------
 // CLS head: final LayerNorm on token 0 + classifier (fp32) -- modeling_vit.py:385,560-561.
 // one block (256 threads) per image.
 // ---------------------------------------------------------------------------------
@@ -344,7 +561,8 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, int T, int D, int C, float eps,
+template <typename XT>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const XT* __restrict__ x, int T, int D, int C, float eps,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ Wc, const float* __restrict__ bc,
                                                        float* __restrict__ xhat_out, float* __restrict__ xf_out,
@@ -353,15 +571,15 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     float* xf = sm;
     float* red = sm + D;
     const int b = blockIdx.x;
-    const float* xr = x + (int64_t)b * T * D;
+    const XT* xr = x + (int64_t)b * T * D;
     float s = 0.f;
-    for (int d = threadIdx.x; d < D; d += 256) s += xr[d];
+    for (int d = threadIdx.x; d < D; d += 256) s += (float)xr[d];
     const float mean = block_sum256(s, red) / D;
     float q = 0.f;
-    for (int d = threadIdx.x; d < D; d += 256) { const float t = xr[d] - mean; q += t * t; }
+    for (int d = threadIdx.x; d < D; d += 256) { const float t = (float)xr[d] - mean; q += t * t; }
     const float rstd = rsqrtf(block_sum256(q, red) / D + eps);
     for (int d = threadIdx.x; d < D; d += 256) {
-        const float xh = (xr[d] - mean) * rstd;
+        const float xh = ((float)xr[d] - mean) * rstd;
         const float v = xh * gamma[d] + beta[d];
         xf[d] = v;
         xhat_out[(int64_t)b * D + d] = xh;
@@ -442,7 +660,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     const float rstd = rstd_in[b];
     for (int d = threadIdx.x; d < D; d += 256) {
         const float o = rstd * (g[d] - c1 - xhat[(int64_t)b * D + d] * c2);
-        dx[(int64_t)b * T * D + d] = o;
+        if (dx) dx[(int64_t)b * T * D + d] = o;
         if (dx_h) dx_h[(int64_t)b * T * D + d] = f2h_sat(o);
     }
 }
@@ -648,7 +866,10 @@ void k_patch_gather(const float* x, h16* out, int B, int S, int P, int normalise
                        normalise, mean[0], mean[1], mean[2], 1.f / std[0], 1.f / std[1], 1.f / std[2]);
 }
 void k_cls_rows(float* x, const float* cls, const float* pos, int B, int T, int D, hipStream_t s) {
-    hipLaunchKernelGGL(cls_rows_kernel, dim3(nblk((int64_t)B * D, 256)), dim3(256), 0, s, x, cls, pos, B, T, D);
+    hipLaunchKernelGGL(cls_rows_kernel<float>, dim3(nblk((int64_t)B * D, 256)), dim3(256), 0, s, x, cls, pos, B, T, D);
+}
+void k_cls_rows16(h16* x, const float* cls, const float* pos, int B, int T, int D, hipStream_t s) {
+    hipLaunchKernelGGL(cls_rows_kernel<h16>, dim3(nblk((int64_t)B * D, 256)), dim3(256), 0, s, x, cls, pos, B, T, D);
 }
 template <int NV>
 static void launch_ln_fwd(dim3 grid, hipStream_t s, const float* x, h16* h, float* mean, float* rstd, const float* g,
@@ -710,8 +931,62 @@ void k_layernorm_bwd(const h16* dh, const float* x, const float* mean, const flo
 void k_head_fwd(const float* x, int B, int T, int D, int C, float eps, const float* g, const float* b, const float* Wc,
                 const float* bc, float* xhat, float* xf, float* rstd, float* logits, hipStream_t s) {
     ProfScope prof_("head_fwd_kernel", 0.0, (double)B * D * 4.0, s);
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), (D + 4) * sizeof(float), s, x, T, D, C, eps, g, b, Wc, bc,
+    hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(B), dim3(256), (D + 4) * sizeof(float), s, x, T, D, C, eps, g, b, Wc, bc,
                        xhat, xf, rstd, logits);
+}
+void k_head_fwd16(const h16* x, int B, int T, int D, int C, float eps, const float* g, const float* b, const float* Wc,
+                  const float* bc, float* xhat, float* xf, float* rstd, float* logits, hipStream_t s) {
+    ProfScope prof_("head_fwd_kernel", 0.0, (double)B * D * 2.0, s);
+    hipLaunchKernelGGL(head_fwd_kernel<h16>, dim3(B), dim3(256), (D + 4) * sizeof(float), s, x, T, D, C, eps, g, b, Wc, bc,
+                       xhat, xf, rstd, logits);
+}
+// ---- 16-bit residual streams ----
+template <int NV>
+static void launch_ln_fwd16(dim3 grid, size_t lds, hipStream_t s, const h16* x, h16* h, float* mean, float* rstd, const float* g,
+                            const float* b, int M, int D, float eps, const h16* delta, h16* xout, const h16* P, int ng, h16* t, int* err) {
+    if (ng == 1) hipLaunchKernelGGL((layernorm_fwd16_kernel<NV, 1>), grid, dim3(256), lds, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, t, err);
+    else if (ng == 2) hipLaunchKernelGGL((layernorm_fwd16_kernel<NV, 2>), grid, dim3(256), lds, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, t, err);
+    else if (ng == 3) hipLaunchKernelGGL((layernorm_fwd16_kernel<NV, 3>), grid, dim3(256), lds, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, t, err);
+    else hipLaunchKernelGGL((layernorm_fwd16_kernel<NV, 0>), grid, dim3(256), 0, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, t, err);
+}
+void k_layernorm_fwd16(const h16* x, h16* h, float* mean, float* rstd, const float* g, const float* b, int M, int D,
+                       float eps, const h16* delta, h16* xout, const h16* P, int ng, h16* t, hipStream_t s, int* err) {
+    if (D % 8 || D > 1024) { fprintf(stderr, "vitlora: LayerNorm (16-bit stream) needs D %% 8 == 0 and D <= 1024\n"); abort(); }
+    ProfScope prof_("layernorm_fwd_kernel", 0.0, (double)M * D * (delta ? (h ? 8.0 : 6.0) : 4.0), s);
+    const int nv = (D / 8 + 31) / 32;
+    if (!P || !t || !h || ng < 0 || ng > 3) ng = 0;
+    dim3 grid(((M + 1) / 2 + 3) / 4);
+    if (ng && grid.x > 1024) grid.x = 1024;          // resident blocks walk the rows, P stays in LDS
+    const size_t lds = (size_t)8 * ng * D * sizeof(h16);
+    switch (nv) {
+        case 1: launch_ln_fwd16<1>(grid, lds, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, ng, t, err); break;
+        case 2: launch_ln_fwd16<2>(grid, lds, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, ng, t, err); break;
+        case 3: launch_ln_fwd16<3>(grid, lds, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, ng, t, err); break;
+        default: launch_ln_fwd16<4>(grid, lds, s, x, h, mean, rstd, g, b, M, D, eps, delta, xout, P, ng, t, err); break;
+    }
+}
+template <int NV>
+static void launch_ln_bwd16(dim3 grid, size_t lds, hipStream_t s, const h16* dh, const h16* x, const float* mean, const float* rstd,
+                            const float* g, h16* dres, int M, int D, const h16* P, int ng, h16* u, int* err) {
+    if (ng == 1) hipLaunchKernelGGL((layernorm_bwd16_kernel<NV, 1>), grid, dim3(256), lds, s, dh, x, mean, rstd, g, dres, M, D, P, u, err);
+    else if (ng == 2) hipLaunchKernelGGL((layernorm_bwd16_kernel<NV, 2>), grid, dim3(256), lds, s, dh, x, mean, rstd, g, dres, M, D, P, u, err);
+    else hipLaunchKernelGGL((layernorm_bwd16_kernel<NV, 0>), grid, dim3(256), 0, s, dh, x, mean, rstd, g, dres, M, D, P, u, err);
+}
+void k_layernorm_bwd16(const h16* dh, const h16* x, const float* mean, const float* rstd, const float* g, h16* dres, int M, int D,
+                       const h16* P, int ng, h16* u, hipStream_t s, int* err) {
+    if (D % 8 || D > 1024) { fprintf(stderr, "vitlora: LayerNorm (16-bit stream) needs D %% 8 == 0 and D <= 1024\n"); abort(); }
+    ProfScope prof_("layernorm_bwd_kernel", 0.0, (double)M * D * 8.0, s);
+    const int nv = (D / 8 + 31) / 32;
+    if (!P || !u || ng < 0 || ng > 2) ng = 0;
+    dim3 grid(((M + 1) / 2 + 3) / 4);
+    if (ng && grid.x > 1024) grid.x = 1024;          // 4 resident blocks per CU walk the rows
+    const size_t lds = (size_t)8 * ng * D * sizeof(h16);
+    switch (nv) {
+        case 1: launch_ln_bwd16<1>(grid, lds, s, dh, x, mean, rstd, g, dres, M, D, P, ng, u, err); break;
+        case 2: launch_ln_bwd16<2>(grid, lds, s, dh, x, mean, rstd, g, dres, M, D, P, ng, u, err); break;
+        case 3: launch_ln_bwd16<3>(grid, lds, s, dh, x, mean, rstd, g, dres, M, D, P, ng, u, err); break;
+        default: launch_ln_bwd16<4>(grid, lds, s, dh, x, mean, rstd, g, dres, M, D, P, ng, u, err); break;
+    }
 }
 void k_ce_loss(const float* logits, const int64_t* labels, int B, int C, float* dlogits, float* loss_img, float* loss,
                int* err, hipStream_t s) {

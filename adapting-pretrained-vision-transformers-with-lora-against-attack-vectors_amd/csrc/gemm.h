@@ -10,7 +10,7 @@ enum GemmEpilogue {
     EPI_RESID_F32 = 1,    // C(f32)  = acc + bias + R(f32)        (R may alias C)
     EPI_GELU = 2,         // z = acc + bias ; C(h16) = gelu(z) ; C2(h16) = gelu'(z)
     EPI_GELU_BWD = 3,     // C(h16) = acc * R(h16), R = the saved gelu'(z)
-    EPI_PATCH_FWD = 4,    // C(f32)[row b*T + 1 + p] = acc + bias + pos[1+p]
+    EPI_PATCH_FWD = 4,    // C(h16)[row b*T + 1 + p] = acc + bias + pos[1+p]   (token rows of the 16-bit residual stream)
     EPI_PATCH_BWD = 5,    // image-layout scatter of d(patches), scaled by 1/std[c]
     EPI_STORE_F32 = 6,    // C(f32) = acc + bias
     EPI_NONE = 7,         // diagnostic: results kept live, nothing stored (timing of the main loop alone)
@@ -62,7 +62,7 @@ static inline double gemm_algo_bytes(const GemmArgs& a, int epi, double rows) {
     if (epi == EPI_RESID_F32) out = 8.0;                // read + write fp32
     else if (epi == EPI_GELU) out = 4.0;                // gelu(z) and gelu'(z), h16 each
     else if (epi == EPI_GELU_BWD) out = 4.0;            // read the saved gelu'(z), write h16
-    else if (epi == EPI_PATCH_FWD || epi == EPI_PATCH_BWD || epi == EPI_STORE_F32) out = 4.0;
+    else if (epi == EPI_PATCH_BWD || epi == EPI_STORE_F32) out = 4.0;
     else if (epi == EPI_PATCH_PGD) out = 12.0;           // read adv, x0; write adv
     else if (epi == EPI_NONE) out = 0.0;
     return 2.0 * rows * K + 2.0 * N * K + rows * N * out + (a.down_W ? rows * 64 * 2.0 : 0.0);

@@ -66,8 +66,10 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
     } else if constexpr (EPI == EPI_PATCH_FWD) {
         if (m < p.Mvalid) {
             const int b = m / p.patches, pi = m - b * p.patches;
+            // the token row of the 16-bit residual stream (round 4; the fp32 parity mode has its own kernels)
             const f32x4 pe = *(const f32x4*)(p.pos + (size_t)(1 + pi) * p.ldc + n);
-            *(f32x4*)((float*)p.C + ((size_t)b * p.tokens + 1 + pi) * p.ldc + n) = v + pe;
+            const f32x4 o = v + pe;
+            *(h16x4*)((h16*)p.C + ((size_t)b * p.tokens + 1 + pi) * p.ldc + n) = h16x4{f2h(o[0]), f2h(o[1]), f2h(o[2]), f2h(o[3])};
         }
     } else if constexpr (EPI == EPI_PATCH_BWD || EPI == EPI_PATCH_PGD) {
         if (m < p.Mvalid) {

@@ -20,13 +20,24 @@ void k_layernorm_bwd(const h16* dh, const float* x, const float* mean, const flo
                      int* err = nullptr, int ldh = 0);   // err: mapped host word, set to 2 when a gradient leaves the fp16 range / is NaN; ldh: row stride of dh / dx_h
 void k_head_fwd(const float* x, int B, int T, int D, int C, float eps, const float* g, const float* b, const float* Wc,
                 const float* bc, float* xhat, float* xf, float* rstd, float* logits, hipStream_t s);
+// ---- 16-bit residual streams (the ViT path's 16-bit precision, round 4): x / x_out / dres are h16 [M, D] ----
+// k_layernorm_fwd16: x_out = round16(x + delta) (delta optional), h = LN(x_out); h == nullptr: the add alone;
+//   err: set to 2 when x + delta leaves the fp16 range.  k_layernorm_bwd16: dres is read and overwritten IN PLACE
+//   (it is the residual-gradient stream and the A operand of the next dgrad GEMM).  P / ng / t|u as above (P staged in LDS).
+void k_cls_rows16(h16* x, const float* cls, const float* pos, int B, int T, int D, hipStream_t s);
+void k_layernorm_fwd16(const h16* x, h16* h, float* mean, float* rstd, const float* g, const float* b, int M, int D,
+                       float eps, const h16* delta, h16* xout, const h16* P, int ng, h16* t, hipStream_t s, int* err = nullptr);
+void k_layernorm_bwd16(const h16* dh, const h16* x, const float* mean, const float* rstd, const float* g, h16* dres, int M, int D,
+                       const h16* P, int ng, h16* u, hipStream_t s, int* err = nullptr);
+void k_head_fwd16(const h16* x, int B, int T, int D, int C, float eps, const float* g, const float* b, const float* Wc,
+                  const float* bc, float* xhat, float* xf, float* rstd, float* logits, hipStream_t s);
 // err: mapped host word; set to 1 when a label is outside [0, C) (that image's loss / dlogits become NaN)
 void k_ce_loss(const float* logits, const int64_t* labels, int B, int C, float* dlogits, float* loss_img, float* loss,
                int* err, hipStream_t s);
 // per-image power-of-two gradient scale of the fp16 backward: gscale[b] = 2^(10 - e), max|dlogits[b]| = f * 2^e with
 // f in [0.5, 1); uniform != 0: one scale for the whole batch (parameter gradients sum over images)
 void k_grad_scale(const float* dlogits, int B, int C, int uniform, float* gscale, float* inv_gscale, hipStream_t s);
-// gscale: per-image factor applied to dlogits (nullptr = 1); dx_h optional
+// gscale: per-image factor applied to dlogits (nullptr = 1); dx and dx_h each optional
 void k_head_bwd(const float* dlogits, const float* gscale, const float* Wc, const float* g, const float* xhat,
                 const float* rstd, int B, int T, int D, int C, float* dx, h16* dx_h, hipStream_t s);
 void k_classifier_grad(const float* dlogits, const float* xf, int B, int D, int C, float* dW, float* db, hipStream_t s);
@@ -70,8 +81,9 @@ int k_attention_img_bwd(const h16* qkv, const h16* ctx, const h16* dctx, const f
 int k_attn_cls_fwd(const h16* qkv, h16* ctx_c, float* lse_c, int B, int T, int H, int D, hipStream_t s);
 int k_attn_cls_bwd(const h16* qkv, const h16* ctx_c, const h16* dctx_c, const float* lse_c, h16* dqkv, int B, int T, int H, int D,
                    hipStream_t s);
-void k_gather_rows(const float* src, float* dst, int B, int D, int64_t stride, hipStream_t s);    // dst[b] = src[b * stride]
-void k_scatter_rows(const float* src, float* dst, int B, int D, int64_t stride, hipStream_t s);   // dst[b * stride] = src[b]
+// rows of the 16-bit residual streams <-> compact fp32 rows
+void k_gather_rows(const h16* src, float* dst, int B, int D, int64_t stride, hipStream_t s);    // dst[b] = src[b * stride]
+void k_scatter_rows(const float* src, h16* dst, int B, int D, int64_t stride, hipStream_t s);   // dst[b * stride] = src[b] (saturating)
 
 // patch.hip: adversarial-patch overlay (warp-and-paste) and its gradient w.r.t. the patch
 void k_patch_overlay(const float* img, const float* patch, const float* mats, float* out, int B, int S, int ps, int circle,

@@ -44,7 +44,8 @@ struct Workspace {
     int max_batch = 0, train = 0;
     int64_t Mpad = 0, Mppad = 0;
     h16* patches;
-    std::vector<float*> xs;          // 2L+1 residual-stream snapshots [Mpad, D]
+    std::vector<float*> xs;          // 2L+1 residual-stream snapshots [Mpad, D] (fp32 parity mode)
+    std::vector<h16*> xs16;          // the same on the 16-bit path: an h16 residual stream (round 4)
     std::vector<float*> mean, rstd;  // 2L
     std::vector<h16*> h1, h2, a;     // per layer in train mode, shared otherwise
     std::vector<h16*> qkv, ctx, z;
@@ -52,8 +53,9 @@ struct Workspace {
     std::vector<h16*> t[4];          // LoRA down outputs (per layer in train mode)
     float *xhat, *xf, *rstd_f, *logits, *dlogits, *loss, *loss_img;
     float *gscale, *inv_gscale;      // per-image power-of-two gradient scale of the 16-bit backward (and its inverse)
-    float* dres[2];
-    h16 *dres_h, *dh, *dctx, *dqkv, *dz, *u;
+    float* dres[2];                  // fp32 mode: residual-gradient stream (ping-pong)
+    h16 *dres_h;                     // 16-bit path: THE residual-gradient stream, updated in place, A operand of the dgrad GEMMs
+    h16 *dh, *dctx, *dqkv, *dz, *u;
     h16* xd;                         // train mode: dropout(x) of the current LoRA branch / dgrad temporary [Mpad, MLP]
     float* grad_img;                 // [max_batch, 3, S, S] for vl_pgd_attack
     // last layer on CLS rows only (cls_path.hip): compact [Bc = round_up(B, 128), .] buffers, 16-bit operand path

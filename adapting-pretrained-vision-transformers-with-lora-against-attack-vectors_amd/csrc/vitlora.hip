@@ -246,7 +246,7 @@ int vl_create(const vl_config* cfg, vl_model** out) {
     m->scaling = m->r ? cfg->lora_alpha / (float)m->r : 0.f;
     const char* ng = getenv("VITLORA_NO_GRAPH");
     m->use_graph = !(ng && ng[0] == '1');
-    { const char* re = getenv("VITLORA_RESID"); m->resid_epi = (re && !strcmp(re, "epilogue")) ? 1 : 0; }
+    m->resid_epi = 0;     // (round 4: the fp32 residual read-modify-write in the GEMM epilogue went away with the fp32 stream)
     { const char* dr = getenv("VITLORA_DEAD_ROWS"); m->dead_rows = !(dr && dr[0] == '0'); }
     { const char* fp = getenv("VITLORA_FUSE_PGD"); m->fuse_pgd = !(fp && fp[0] == '0'); }
     { const char* fk = getenv("VITLORA_FUSE_DOWN_MIN_K"); if (fk) m->fuse_down_min_k = atoi(fk); }
@@ -490,9 +490,11 @@ static size_t carve(vl_model* m, int B, int train, char* base) {
         return p;
     };
     w.Mpad = Mpad; w.Mppad = Mppad;
-    // ---- common to both precisions: fp32 residual stream, statistics, head, gradient stream, attack staging ----
-    w.xs.resize(2 * L + 1);
-    for (auto& p : w.xs) p = (float*)take((size_t)Mpad * D * 4);
+    // ---- common to both precisions: statistics, head, attack staging; the residual stream and its gradient stream are
+    // fp32 in the fp32 parity mode and h16 on the 16-bit path (round 4: a LayerNorm pass moves 8 B per element, not 12 / 16) ----
+    w.xs.assign(2 * L + 1, nullptr); w.xs16.assign(2 * L + 1, nullptr);
+    if (m->f32) for (auto& p : w.xs) p = (float*)take((size_t)Mpad * D * 4);
+    else for (auto& p : w.xs16) p = (h16*)take((size_t)Mpad * D * 2);
     w.mean.resize(2 * L); w.rstd.resize(2 * L);
     for (int i = 0; i < 2 * L; ++i) { w.mean[i] = (float*)take(Mpad * 4); w.rstd[i] = (float*)take(Mpad * 4); }
     w.lse.resize(L);
@@ -503,7 +505,8 @@ static size_t carve(vl_model* m, int B, int train, char* base) {
     w.loss = (float*)take(256);
     w.loss_img = (float*)take((size_t)B * 4);
     w.gscale = (float*)take((size_t)B * 4); w.inv_gscale = (float*)take((size_t)B * 4);
-    w.dres[0] = (float*)take((size_t)Mpad * D * 4); w.dres[1] = (float*)take((size_t)Mpad * D * 4);
+    w.dres[0] = w.dres[1] = nullptr;
+    if (m->f32) { w.dres[0] = (float*)take((size_t)Mpad * D * 4); w.dres[1] = (float*)take((size_t)Mpad * D * 4); }
     const size_t img = (size_t)B * 3 * m->S * m->S * 4;
     w.grad_img = (float*)take(img);
     w.stage_x0 = (float*)take(img); w.stage_adv = (float*)take(img);
@@ -602,26 +605,25 @@ static int forward_impl(vl_model* m, const float* x, int B, int normalise, int t
     k_patch_gather(x, w.patches, B, m->S, m->P, normalise, m->mean, m->stdv, s);
     {
         GemmArgs g = gemm_args(w.patches, m->PK, m->Wpe, m->PK, m->PK, Mppad, D);
-        g.Mvalid = B * m->NP; g.bias = m->bpe; g.C = w.xs[0]; g.ldc = D;
+        g.Mvalid = B * m->NP; g.bias = m->bpe; g.C = w.xs16[0]; g.ldc = D;
         g.pos = m->pos; g.tokens = T; g.patches = m->NP;
         launch_gemm(g, EPI_PATCH_FWD, 128, s);
     }
-    k_cls_rows(w.xs[0], m->cls, m->pos, B, T, D, s);
-    // residual stream: the o / fc2 projections store their output (bias and LoRA included) as h16 and the
-    // LayerNorm that follows adds it to the fp32 stream while it normalises (one pass over x instead of a
-    // 4 + 4 B/element read-modify-write in the GEMM epilogue, which the MFMA loop cannot hide)
+    k_cls_rows16(w.xs16[0], m->cls, m->pos, B, T, D, s);
+    // residual stream (h16): the o / fc2 projections store their output (bias and LoRA included) as
+    // h16 and the LayerNorm that follows adds it to the stream while it normalises: x' = round16(x + delta), h = LN(x')
     h16* delta = w.dres_h;                         // backward scratch, idle during the forward
-    const bool re = m->resid_epi;
+    int* const ef = m->err_flag;
     // eval-mode forwards only feed logits and input gradients: the last layer runs on the CLS rows alone
-    const bool cls_only = m->dead_rows && !train && !re;
+    const bool cls_only = m->dead_rows && !train;
     m->cur_cls_only = 0;
     for (int l = 0; l < L; ++l) {
         Layer& ly = m->layers[l];
         GemmArgs g;
         const int n1 = fused_down_fwd(m, ly.lin[LQKV]);      // t of the qkv projection comes out of LN1
         const h16* P1 = n1 ? ly.lin[LQKV].Ad : nullptr;
-        if (l == 0 || re) k_layernorm_fwd(w.xs[2 * l], w.h1[l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, ly.ln1_b, M, D, m->cfg.ln_eps, nullptr, nullptr, P1, n1, w.t[LQKV][l], s);
-        else k_layernorm_fwd(w.xs[2 * l - 1], w.h1[l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, ly.ln1_b, M, D, m->cfg.ln_eps, delta, w.xs[2 * l], P1, n1, w.t[LQKV][l], s);
+        if (l == 0) k_layernorm_fwd16(w.xs16[2 * l], w.h1[l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, ly.ln1_b, M, D, m->cfg.ln_eps, nullptr, nullptr, P1, n1, w.t[LQKV][l], s, ef);
+        else k_layernorm_fwd16(w.xs16[2 * l - 1], w.h1[l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, ly.ln1_b, M, D, m->cfg.ln_eps, delta, w.xs16[2 * l], P1, n1, w.t[LQKV][l], s, ef);
         memset(&g, 0, sizeof g); g.C = w.qkv[l]; g.ldc = 3 * D;
         linear_fwd(m, ly.lin[LQKV], w.h1[l], w.t[LQKV][l], Mpad, g, EPI_STORE_H16, s, l * 4 + LQKV, n1 > 0);
         if (cls_only && l == L - 1) {
@@ -632,7 +634,7 @@ static int forward_impl(vl_model* m, const float* x, int B, int normalise, int t
             m->cur_M = B;                                          // rows the compact GEMMs may store
             memset(&g, 0, sizeof g); g.C = c.delta; g.ldc = D;
             linear_fwd(m, ly.lin[LO], c.ctx, c.t, Bc, g, EPI_STORE_H16, s, l * 4 + LO);
-            k_gather_rows(w.xs[2 * l], c.x0, B, D, (int64_t)T * D, s);
+            k_gather_rows(w.xs16[2 * l], c.x0, B, D, (int64_t)T * D, s);
             const int n2c = fused_down_fwd(m, ly.lin[LFC1]);
             k_layernorm_fwd(c.x0, c.h2, c.mean, c.rstd, ly.ln2_g, ly.ln2_b, B, D, m->cfg.ln_eps, c.delta, c.x1,
                             n2c ? ly.lin[LFC1].Ad : nullptr, n2c, c.t, s);
@@ -656,20 +658,17 @@ static int forward_impl(vl_model* m, const float* x, int B, int normalise, int t
                 return fail(VL_ERR_UNSUPPORTED, "attention: T > 224");
         } else if (k_attention32_fwd(w.qkv[l], w.ctx[l], w.lse[l], B, T, m->H, D, s)) return fail(VL_ERR_UNSUPPORTED, "attention: T > 224");
         memset(&g, 0, sizeof g); g.C = delta; g.ldc = D;
-        if (re) { g.C = w.xs[2 * l + 1]; g.R = w.xs[2 * l]; g.ldr = D; }
-        linear_fwd(m, ly.lin[LO], w.ctx[l], w.t[LO][l], Mpad, g, re ? EPI_RESID_F32 : EPI_STORE_H16, s, l * 4 + LO, t_o);
+        linear_fwd(m, ly.lin[LO], w.ctx[l], w.t[LO][l], Mpad, g, EPI_STORE_H16, s, l * 4 + LO, t_o);
         const int n2 = fused_down_fwd(m, ly.lin[LFC1]);      // t of fc1 (r columns) comes out of LN2
         const h16* P2 = n2 ? ly.lin[LFC1].Ad : nullptr;
-        if (re) k_layernorm_fwd(w.xs[2 * l + 1], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D, m->cfg.ln_eps, nullptr, nullptr, P2, n2, w.t[LFC1][l], s);
-        else k_layernorm_fwd(w.xs[2 * l], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D, m->cfg.ln_eps, delta, w.xs[2 * l + 1], P2, n2, w.t[LFC1][l], s);
+        k_layernorm_fwd16(w.xs16[2 * l], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D, m->cfg.ln_eps, delta, w.xs16[2 * l + 1], P2, n2, w.t[LFC1][l], s, ef);
         memset(&g, 0, sizeof g); g.C = w.a[l]; g.ldc = m->MLP; g.C2 = w.z[l]; g.ldc2 = m->MLP;
         linear_fwd(m, ly.lin[LFC1], w.h2[l], w.t[LFC1][l], Mpad, g, EPI_GELU, s, l * 4 + LFC1, n2 > 0);
         memset(&g, 0, sizeof g); g.C = delta; g.ldc = D;
-        if (re) { g.C = w.xs[2 * l + 2]; g.R = w.xs[2 * l + 1]; g.ldr = D; }
-        linear_fwd(m, ly.lin[LFC2], w.a[l], w.t[LFC2][l], Mpad, g, re ? EPI_RESID_F32 : EPI_STORE_H16, s, l * 4 + LFC2);
+        linear_fwd(m, ly.lin[LFC2], w.a[l], w.t[LFC2][l], Mpad, g, EPI_STORE_H16, s, l * 4 + LFC2);
     }
-    if (!re) k_layernorm_fwd(w.xs[2 * L - 1], nullptr, nullptr, nullptr, nullptr, nullptr, M, D, m->cfg.ln_eps, delta, w.xs[2 * L], nullptr, 0, nullptr, s);
-    k_head_fwd(w.xs[2 * L], B, T, D, m->C, m->cfg.ln_eps, m->lnf_g, m->lnf_b, m->flat + m->cls_w_off,
+    k_layernorm_fwd16(w.xs16[2 * L - 1], nullptr, nullptr, nullptr, nullptr, nullptr, M, D, m->cfg.ln_eps, delta, w.xs16[2 * L], nullptr, 0, nullptr, s, ef);
+    k_head_fwd16(w.xs16[2 * L], B, T, D, m->C, m->cfg.ln_eps, m->lnf_g, m->lnf_b, m->flat + m->cls_w_off,
                m->flat + m->cls_b_off, w.xhat, w.xf, w.rstd_f, w.logits, s);
     m->cur_B = B; m->cur_norm = normalise; m->cur_train = train; m->have_loss = 0;
     return VL_OK;
@@ -726,13 +725,12 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
         HIPCHK(hipMemsetAsync(flat_grad, 0, (size_t)m->flat_n * sizeof(float), s));
         k_classifier_grad(w.dlogits, w.xf, B, D, m->C, flat_grad + m->cls_w_off, flat_grad + m->cls_b_off, s);
     }
-    int cur = 0;
     const bool cls_only = m->cur_cls_only != 0;
     if (cls_only && flat_grad) return fail(VL_ERR_STATE, "parameter gradients need a train-mode forward");
     if (!cls_only) {
-        k_zero(w.dres[0], (size_t)Mpad * D * sizeof(float), s);       // kernel nodes, not memset nodes: section 3.3 of DESIGN.md
-        k_zero(w.dres_h, (size_t)Mpad * D * sizeof(h16), s);
-        k_head_bwd(w.dlogits, w.gscale, m->flat + m->cls_w_off, m->lnf_g, w.xhat, w.rstd_f, B, T, D, m->C, w.dres[0], w.dres_h, s);
+        // the residual-gradient stream (h16, updated in place by every LayerNorm backward; also the A operand of the dgrad GEMMs)
+        k_zero(w.dres_h, (size_t)Mpad * D * sizeof(h16), s);       // a kernel node, not a memset node: section 3.3 of DESIGN.md
+        k_head_bwd(w.dlogits, w.gscale, m->flat + m->cls_w_off, m->lnf_g, w.xhat, w.rstd_f, B, T, D, m->C, nullptr, w.dres_h, s);
     }
 
     // LoRA weight gradients of one projection: dy [M,out], x [M,in], t/u [M,kext]
@@ -773,12 +771,11 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
             memset(&g, 0, sizeof g); g.C = w.dh; g.ldc = D;
             linear_dgrad(m, ly.lin[LQKV], w.dqkv, w.u, Mpad, g, EPI_STORE_H16, s, l * 4 + LQKV);
             // residual gradient entering LN1: zero except the CLS rows
-            k_zero(w.dres[cur], (size_t)Mpad * D * sizeof(float), s);
-            k_scatter_rows(c.dres[1], w.dres[cur], B, D, (int64_t)T * D, s);
+            k_zero(w.dres_h, (size_t)Mpad * D * sizeof(h16), s);
+            k_scatter_rows(c.dres[1], w.dres_h, B, D, (int64_t)T * D, s);
             const int ffc = l > 0 ? fused_down(m, m->layers[l - 1].lin[LFC2]) : 0;
-            k_layernorm_bwd(w.dh, w.xs[2 * l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, w.dres[cur], w.dres[cur ^ 1], w.dres_h,
-                            M, D, ffc ? m->layers[l - 1].lin[LFC2].Bd : nullptr, ffc, w.u, s, m->err_flag);
-            cur ^= 1;
+            k_layernorm_bwd16(w.dh, w.xs16[2 * l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, w.dres_h,
+                              M, D, ffc ? m->layers[l - 1].lin[LFC2].Bd : nullptr, ffc, w.u, s, m->err_flag);
             continue;
         }
         // MLP: dz = (dx2 Wfc2 (+LoRA)) * gelu'(z)
@@ -790,9 +787,8 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
         linear_dgrad(m, ly.lin[LFC1], w.dz, w.u, Mpad, g, EPI_STORE_H16, s, l * 4 + LFC1);
         wgrad(ly.lin[LFC1], w.dz, w.h2[l], w.t[LFC1][l], w.u, l * 4 + LFC1);
         const int fo = fused_down(m, ly.lin[LO]);
-        k_layernorm_bwd(w.dh, w.xs[2 * l + 1], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, w.dres[cur], w.dres[cur ^ 1],
-                        w.dres_h, M, D, ly.lin[LO].Bd, fo, w.u, s, m->err_flag);
-        cur ^= 1;
+        k_layernorm_bwd16(w.dh, w.xs16[2 * l + 1], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, w.dres_h, M, D, ly.lin[LO].Bd, fo, w.u, s,
+                          m->err_flag);
         // attention block
         memset(&g, 0, sizeof g); g.C = w.dctx; g.ldc = D;
         linear_dgrad(m, ly.lin[LO], w.dres_h, w.u, Mpad, g, EPI_STORE_H16, s, l * 4 + LO, fo > 0);
@@ -811,10 +807,8 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
         linear_dgrad(m, ly.lin[LQKV], w.dqkv, w.u, Mpad, g, EPI_STORE_H16, s, l * 4 + LQKV, u_qkv);
         wgrad(ly.lin[LQKV], w.dqkv, w.h1[l], w.t[LQKV][l], w.u, l * 4 + LQKV);
         const int ff = l > 0 ? fused_down(m, m->layers[l - 1].lin[LFC2]) : 0;     // next consumer: fc2 dgrad of the layer below
-        // (layer 0: the fp32 residual gradient has no reader below -- the patch-embedding dgrad consumes the h16 copy)
-        k_layernorm_bwd(w.dh, w.xs[2 * l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, w.dres[cur], l > 0 ? w.dres[cur ^ 1] : nullptr, w.dres_h,
-                        M, D, ff ? m->layers[l - 1].lin[LFC2].Bd : nullptr, ff, w.u, s, m->err_flag);
-        cur ^= 1;
+        k_layernorm_bwd16(w.dh, w.xs16[2 * l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, w.dres_h, M, D,
+                          ff ? m->layers[l - 1].lin[LFC2].Bd : nullptr, ff, w.u, s, m->err_flag);
     }
     if (grad_x || pf) {
         // d(pixels): patch rows of d(x0) times Wpe, scattered back to NCHW, chain rule of (x-mean)/std
@@ -1288,7 +1282,7 @@ int vl_debug_tensor(vl_model* m, const char* what, int layer, void** ptr, int64_
     {   // backward-side buffers (shared across layers: they hold what the LAST executed kernel sequence left) and the head
         const int64_t Mp = w.Mpad, img = (int64_t)m->cur_B * 3 * m->S * m->S;
         struct { const char* name; void* p; int64_t n; int dt; } extra[] = {
-            {"dres0", w.dres[0], Mp * m->D, 0}, {"dres1", w.dres[1], Mp * m->D, 0}, {"grad_img", w.grad_img, img, 0},
+            {"dres0", w.dres[0], Mp * m->D, 0}, {"dres1", w.dres[1], Mp * m->D, 0}, {"grad_img", w.grad_img, img, 0},   // fp32 mode only
             {"stage_adv", w.stage_adv, img, 0}, {"stage_x0", w.stage_x0, img, 0},
             {"logits", w.logits, (int64_t)m->cur_B * m->C, 0}, {"dlogits", w.dlogits, (int64_t)m->cur_B * m->C, 0},
             {"gscale", w.gscale, m->cur_B, 0}, {"inv_gscale", w.inv_gscale, m->cur_B, 0}, {"loss_img", w.loss_img, m->cur_B, 0},
@@ -1304,7 +1298,10 @@ int vl_debug_tensor(vl_model* m, const char* what, int layer, void** ptr, int64_
                 *ptr = e.p; *numel = e.n; *dtype = e.dt; return VL_OK;
             }
     }
-    if (!strcmp(what, "xs")) { if (layer < 0 || layer > 2 * m->L) return fail(VL_ERR_ARG, "index"); *ptr = w.xs[layer]; *numel = MD; *dtype = 0; return VL_OK; }
+    if (!strcmp(what, "xs")) {       // residual-stream snapshots: fp32 in the fp32 mode, h16 on the 16-bit path
+        if (layer < 0 || layer > 2 * m->L) return fail(VL_ERR_ARG, "index");
+        *ptr = m->f32 ? (void*)w.xs[layer] : (void*)w.xs16[layer]; *numel = MD; *dtype = m->f32 ? 0 : 1; return VL_OK;
+    }
     if (layer < 0 || layer >= m->L) return fail(VL_ERR_ARG, "layer out of range");
     if (m->f32) {
         if (!strcmp(what, "qkv")) { *ptr = w.f_qkv[layer]; *numel = 3 * MD; *dtype = 0; return VL_OK; }

@@ -223,7 +223,8 @@ class _RoundBwdOnly(torch.autograd.Function):
 # ``sim`` is False (fp32 arithmetic), True (every site rounded) or a collection of site names:
 # only those sites are rounded (error-budget experiments, tools/error_budget.py).  A name with the
 # suffix ":f" / ":b" rounds only the forward value / only the gradient at that site.
-SITES = ("patches", "h", "qkv", "probs", "ctx", "delta", "act", "gelu_prime", "dz", "t", "weights", "lora_w")
+# "resid" (round 4): the residual stream and the residual-gradient stream are 16-bit tensors on the HIP path.
+SITES = ("patches", "h", "qkv", "probs", "ctx", "delta", "act", "gelu_prime", "dz", "t", "weights", "lora_w", "resid")
 
 
 def _on(sim, site):
@@ -312,7 +313,7 @@ def vit_forward(w: Dict[str, torch.Tensor], cfg: OracleConfig, x_norm: torch.Ten
     Wpe = w["vit.embeddings.patch_embeddings.projection.weight"].reshape(D, 3 * P * P)
     emb = F.linear(patches, _wq(Wpe, sim), w["vit.embeddings.patch_embeddings.projection.bias"])
     x = torch.cat([w["vit.embeddings.cls_token"].expand(B, -1, -1), emb], dim=1)
-    x = x + w["vit.embeddings.position_embeddings"]
+    x = _rb(x + w["vit.embeddings.position_embeddings"], sim, "resid")
     if trace is not None:
         trace["xs0"] = x.detach()
     sc = lora.scaling if lora is not None else 0.0
@@ -343,13 +344,14 @@ def vit_forward(w: Dict[str, torch.Tensor], cfg: OracleConfig, x_norm: torch.Ten
         if trace is not None:
             trace[f"qkv{i}"] = torch.cat([t_.transpose(1, 2).reshape(B, N, D) for t_ in (q, k_, v)], dim=-1).detach()
             trace[f"ctx{i}"] = ctx.detach()
-        x = x + _rb(lin("o", ctx), sim, "delta")       # projection output held in 16 bits, added by the next LN pass
+        # projection output held in 16 bits, added by the next LN pass; the sum is stored in 16 bits (and normalised as stored)
+        x = _rb(x + _rb(lin("o", ctx), sim, "delta"), sim, "resid")
         if trace is not None:
             trace[f"xs{2 * i + 1}"] = x.detach()
         h2 = _rb(F.layer_norm(x, (D,), w[p + "layernorm_after.weight"],
                               w[p + "layernorm_after.bias"], cfg.ln_eps), sim, "h")
         a = gelu_sim(lin("fc1", h2), sim)          # exact erf GELU (hidden_act="gelu")
-        x = x + _rb(lin("fc2", a), sim, "delta")
+        x = _rb(x + _rb(lin("fc2", a), sim, "delta"), sim, "resid")
         if trace is not None:
             trace[f"xs{2 * i + 2}"] = x.detach()
     xf = F.layer_norm(x[:, 0], (D,), w["vit.layernorm.weight"], w["vit.layernorm.bias"], cfg.ln_eps)

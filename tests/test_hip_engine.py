@@ -61,7 +61,8 @@ def test_forward_stagewise(image_size, batch, with_lora, prec):
         eng.set_dead_rows(True)
         logits2 = eng.forward(xn.cuda(), normalise=False)
         torch.cuda.synchronize()
-        assert rel_l2(logits2.cpu(), logits.cpu()) < 5e-4 and rel_l2(logits2.cpu(), tr["logits"]) < TOL_ACT[prec]
+        # (the compact CLS rows keep an fp32 stream through the last layer, the full-row route rounds it to 16 bits twice more)
+        assert rel_l2(logits2.cpu(), logits.cpu()) < 1.5e-3 and rel_l2(logits2.cpu(), tr["logits"]) < TOL_ACT[prec]
         L2 = 2 * cfg.layers
         for name, ref in (("cls_x1", tr[f"xs{L2 - 1}"][:, 0]), ("cls_x2", tr[f"xs{L2}"][:, 0])):
             got = eng.debug_tensor(name, 0).float().cpu().view(B, D)
@@ -417,25 +418,3 @@ def test_main_gemm_kernels_agree_bitwise(shape):
             assert d.value <= (4e-3 if epi == 2 else 0.0), (name, mode, d.value)
 
 
-def test_residual_add_in_the_gemm_epilogue_mode(monkeypatch):
-    """VITLORA_RESID=epilogue (read when the handle is created): o-proj and fc2 add the fp32 residual in their GEMM epilogue
-    (fp32 output in the natural MFMA column order) instead of handing a 16-bit delta to the next LayerNorm.  Same tolerances
-    as the default placement, and the two placements agree to fp16 rounding."""
-    cfg, w, lora, x, y = make_case(image_size=224, hidden=256, heads=4, mlp=1024, layers=2, batch=3, r=8)
-    _, g_ref, lg_ref = O.loss_and_input_grad(w, cfg, x, y, lora)
-    outs = []
-    for mode in ("epilogue", None):
-        if mode:
-            monkeypatch.setenv("VITLORA_RESID", mode)
-        else:
-            monkeypatch.delenv("VITLORA_RESID", raising=False)
-        eng = make_engine(cfg, w, lora, precision="f16")
-        logits = eng.forward(x.cuda(), normalise=True).cpu()
-        eng.loss_ce(y.cuda())
-        gx, _ = eng.backward(True, False, tuple(x.shape))
-        torch.cuda.synchronize()
-        assert rel_l2(logits, lg_ref) < TOL_ACT["f16"], mode
-        assert rel_l2(gx.cpu(), g_ref) < TOL_GRAD["f16"], mode
-        outs.append((logits, gx.cpu()))
-    assert rel_l2(outs[0][0], outs[1][0]) < 2e-3 and rel_l2(outs[0][1], outs[1][1]) < 3e-3
-    assert not torch.equal(outs[0][0], outs[1][0])       # the switch really selected another path
