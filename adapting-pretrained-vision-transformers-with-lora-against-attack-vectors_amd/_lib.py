@@ -67,6 +67,7 @@ SIGNATURES = {
     "vl_debug_set_gemm_stream": (C.c_int, [C.c_int]),
     "vl_debug_set_cus": (C.c_int, [C.c_void_p, C.c_int]),
     "vl_check_errors": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vl_swin_check_errors": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vl_debug_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "vl_profile_begin": (C.c_int, []),
     "vl_profile_report": (C.c_int, [C.c_char_p, C.c_size_t]),

@@ -58,6 +58,7 @@ __device__ unsigned long long g_attn_stamps[8192 * 8 * 8];
 namespace {
 
 constexpr int HD = 64;
+#define TPAD(t) ((double)(((t) + 31) / 32 * 32))      // executed-FLOP accounting: the kernels work on 32-token tiles
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -1463,7 +1464,7 @@ int attention32_init(int device) {
 }
 
 int k_attention32_fwd(const h16* qkv, h16* ctx, float* lse2, int B, int T, int H, int D, hipStream_t s) {
-    ProfScope prof_("attn_fwd32_kernel", 4.0 * B * H * (double)T * T * HD, (double)B * T * D * 8.0, s);
+    ProfScope prof_("attn_fwd32_kernel", 4.0 * B * H * (double)T * T * HD, (double)B * T * D * 8.0, s, 4.0 * B * H * (double)TPAD(T) * TPAD(T) * HD);
     const float sl = 0.125f * 1.4426950408889634f;
     if (T <= 32) hipLaunchKernelGGL((attn_fwd32_kernel<1>), dim3(B * H), dim3(64 * FWD_WAVES), 0, s, qkv, ctx, lse2, T, H, D, sl);
     else if (T <= 224) hipLaunchKernelGGL((attn_fwd32_kernel<7>), dim3(B * H), dim3(64 * FWD_WAVES), 0, s, qkv, ctx, lse2, T, H, D, sl);
@@ -1473,7 +1474,7 @@ int k_attention32_fwd(const h16* qkv, h16* ctx, float* lse2, int B, int T, int H
 
 int k_attention32_bwd(const h16* qkv, const h16* ctx, const h16* dctx, const float* lse2, h16* dqkv, int B, int T,
                       int H, int D, hipStream_t s) {
-    ProfScope prof_("attn_bwd32_kernel", 10.0 * B * H * (double)T * T * HD, (double)B * T * D * 16.0, s);
+    ProfScope prof_("attn_bwd32_kernel", 10.0 * B * H * (double)T * T * HD, (double)B * T * D * 16.0, s, 10.0 * B * H * (double)TPAD(T) * TPAD(T) * HD);
     if (T <= 32) launch_bwd<1>(qkv, ctx, dctx, lse2, dqkv, B, T, H, D, s);
     else if (T <= 224) launch_bwd<7>(qkv, ctx, dctx, lse2, dqkv, B, T, H, D, s);
     else return -1;
@@ -1485,7 +1486,7 @@ int k_attention32_bwd(const h16* qkv, const h16* ctx, const h16* dctx, const flo
 // fused q / k / v projection (backward, u = dqkv Bd^T); W == nullptr: attention only.  r <= 8.
 int k_attention_img_fwd(const h16* qkv, h16* ctx, float* lse2, int B, int T, int H, int D, const h16* Ad, h16* t, int r,
                         hipStream_t s) {
-    ProfScope prof_("attn_fwd_img_kernel", 4.0 * B * H * (double)T * T * HD, (double)B * T * D * 8.0, s);
+    ProfScope prof_("attn_fwd_img_kernel", 4.0 * B * H * (double)T * T * HD, (double)B * T * D * 8.0, s, 4.0 * B * H * (double)TPAD(T) * TPAD(T) * HD);
     LoraDown lo;
     lo.W = Ad; lo.out = t; lo.r = r; lo.mods = 1u;
     if (!Ad || !t || r <= 0 || r > 8) { lo.W = nullptr; lo.out = nullptr; }
@@ -1497,7 +1498,9 @@ int k_attention_img_fwd(const h16* qkv, h16* ctx, float* lse2, int B, int T, int
 int k_attention_img_bwd(const h16* qkv, const h16* ctx, const h16* dctx, const float* lse2, h16* dqkv, int B, int T, int H, int D,
                         const h16* Bd, h16* u, int r, unsigned mods, hipStream_t s) {
     const bool ring = g_attn_ring && T <= (T <= 32 ? ring_img_rows<1>() : ring_img_rows<7>());      // the kernel launch_bwd_img picks
-    ProfScope prof_(ring ? "attn_bwd_ring_kernel" : "attn_bwd_img_kernel", 10.0 * B * H * (double)T * T * HD, (double)B * T * D * 16.0, s);
+    // executed: the ring form issues 5 products per 32 x 32 tile pair (S, dP, dV, dK, dQ), the two-phase form 7 (S and dP twice)
+    ProfScope prof_(ring ? "attn_bwd_ring_kernel" : "attn_bwd_img_kernel", 10.0 * B * H * (double)T * T * HD, (double)B * T * D * 16.0, s,
+                    (ring ? 10.0 : 14.0) * B * H * (double)TPAD(T) * TPAD(T) * HD);
     LoraDown lo;
     lo.W = Bd; lo.out = u; lo.r = r; lo.mods = mods;
     if (!Bd || !u || r <= 0 || r > 8 || !mods) { lo.W = nullptr; lo.out = nullptr; }

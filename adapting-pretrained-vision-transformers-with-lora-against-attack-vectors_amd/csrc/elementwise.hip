@@ -952,7 +952,7 @@ static void launch_ln_fwd16(dim3 grid, size_t lds, hipStream_t s, const h16* x, 
 void k_layernorm_fwd16(const h16* x, h16* h, float* mean, float* rstd, const float* g, const float* b, int M, int D,
                        float eps, const h16* delta, h16* xout, const h16* P, int ng, h16* t, hipStream_t s, int* err) {
     if (D % 8 || D > 1024) { fprintf(stderr, "vitlora: LayerNorm (16-bit stream) needs D %% 8 == 0 and D <= 1024\n"); abort(); }
-    ProfScope prof_("layernorm_fwd_kernel", 0.0, (double)M * D * (delta ? (h ? 8.0 : 6.0) : 4.0), s);
+    ProfScope prof_("layernorm_fwd16_kernel", 0.0, (double)M * D * (delta ? (h ? 8.0 : 6.0) : 4.0), s);
     const int nv = (D / 8 + 31) / 32;
     if (!P || !t || !h || ng < 0 || ng > 3) ng = 0;
     dim3 grid(((M + 1) / 2 + 3) / 4);
@@ -975,7 +975,7 @@ static void launch_ln_bwd16(dim3 grid, size_t lds, hipStream_t s, const h16* dh,
 void k_layernorm_bwd16(const h16* dh, const h16* x, const float* mean, const float* rstd, const float* g, h16* dres, int M, int D,
                        const h16* P, int ng, h16* u, hipStream_t s, int* err) {
     if (D % 8 || D > 1024) { fprintf(stderr, "vitlora: LayerNorm (16-bit stream) needs D %% 8 == 0 and D <= 1024\n"); abort(); }
-    ProfScope prof_("layernorm_bwd_kernel", 0.0, (double)M * D * 8.0, s);
+    ProfScope prof_("layernorm_bwd16_kernel", 0.0, (double)M * D * 8.0, s);
     const int nv = (D / 8 + 31) / 32;
     if (!P || !u || ng < 0 || ng > 2) ng = 0;
     dim3 grid(((M + 1) / 2 + 3) / 4);

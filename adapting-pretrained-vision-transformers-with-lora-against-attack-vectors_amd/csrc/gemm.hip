@@ -235,7 +235,7 @@ void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
         return;
     }
     snprintf(name, sizeof name, "gemm_nt_kernel<128, %d, %d>", bn == 64 ? 64 : 128, epi);
-    ProfScope prof_(name, flops, gemm_algo_bytes(a, epi, mv), s);
+    ProfScope prof_(name, flops, gemm_algo_bytes(a, epi, mv), s, 2.0 * a.M * a.N * (a.K1 + a.K2));
     if (bn == 64) {
         switch (epi) {
             // skinny LoRA-down product (HBM-bound on A): 64-row tiles -> 3x more workgroups in flight

@@ -388,8 +388,9 @@ void launch_one(const GemmArgs& a, int ntiles, int bm0, hipStream_t s) {
     snprintf(name, sizeof name, "gemm256_kernel<%d, %d>", BM, EPI);
     const double rows = (double)(ntiles / (a.N / BN)) * BM;
     const double valid = a.Mvalid ? (double)a.Mvalid / a.M : 1.0;
+    const double k2x = a.K2 ? (a.k2_used > 0 && a.k2_used <= 32 ? 32.0 : (double)a.K2) : 0.0;     // the zero upper half of the LoRA tile is skipped
     ProfScope prof_(name, 2.0 * rows * valid * (a.n_algo ? a.n_algo : a.N) * (a.K1 + (a.k2_algo ? a.k2_algo : a.K2)),
-                    gemm_algo_bytes(a, EPI, rows * valid), s);
+                    gemm_algo_bytes(a, EPI, rows * valid), s, 2.0 * rows * a.N * (a.K1 + k2x));
     const int grid = ntiles < g_num_cus ? ntiles : g_num_cus;
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(h16) + 1024;
     hipLaunchKernelGGL((gemm256_kernel<BM, EPI>), dim3(grid), dim3(512), lds, s, a, ntiles, bm0);

@@ -453,7 +453,7 @@ void launch_pp(const GemmArgs& a, hipStream_t s) {
     else snprintf(name, sizeof name, "gemm_pp_kernel<%d>", EPI);
     const double valid = a.Mvalid ? (double)a.Mvalid / a.M : 1.0;
     ProfScope prof_(name, 2.0 * a.M * valid * (a.n_algo ? a.n_algo : a.N) * (a.K1 + (a.k2_algo ? a.k2_algo : a.K2)),
-                    gemm_algo_bytes(a, EPI, a.M * valid), s);
+                    gemm_algo_bytes(a, EPI, a.M * valid), s, 2.0 * a.M * a.N * (a.K1 + a.K2 + (ND ? 64 : 0)) + (ND ? 2.0 * a.M * 16.0 * ND * a.K1 : 0.0));
     const int units = (ntiles + 1) / 2;
     const int grid = units < g_pp_cus ? (ntiles < g_pp_cus ? ntiles : g_pp_cus) : g_pp_cus;
     const size_t lds = (size_t)NSTAGE * stg_of(ND) * sizeof(h16) + 1024;

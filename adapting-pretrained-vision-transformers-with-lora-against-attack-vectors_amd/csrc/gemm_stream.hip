@@ -374,7 +374,7 @@ void launch_gemm_stream(const GemmArgs& a, int epi, int bn, hipStream_t s) {
     const double flops = 2.0 * mv * (a.n_algo ? a.n_algo : a.N) * (a.K1 + (a.k2_algo ? a.k2_algo : a.K2));
     char name[64];
     snprintf(name, sizeof name, "gemm_stream_kernel<%d, %d, %s>", bn == 64 ? 64 : 128, epi, a.down_W ? "true" : "false");    // as rocprofv3 prints it
-    ProfScope prof_(name, flops, gemm_algo_bytes(a, epi, mv), s);
+    ProfScope prof_(name, flops, gemm_algo_bytes(a, epi, mv), s, 2.0 * a.M * a.N * (a.K1 + a.K2 + (a.down_W ? 64 : 0)) + (a.down_W ? 2.0 * a.M * 64.0 * a.K1 : 0.0));
     if (a.down_W) {
         if (epi == EPI_STORE_H16) launch_s<128, EPI_STORE_H16, true>(a, s);
         else launch_s<128, EPI_GELU_BWD, true>(a, s);

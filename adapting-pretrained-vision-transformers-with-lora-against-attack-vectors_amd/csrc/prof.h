@@ -9,6 +9,7 @@
 struct ProfRecord {
     std::string name;
     double flops, bytes;
+    double exec_flops;      // FLOPs the matrix pipes are asked to execute (padded rows / tiles, the whole LoRA K tile); < 0: = flops
     hipEvent_t e0, e1;
 };
 
@@ -21,10 +22,10 @@ extern Profiler* g_prof;   // defined in vitlora.hip; non-null only between begi
 struct ProfScope {
     hipStream_t s;
     hipEvent_t e1 = nullptr;
-    ProfScope(const char* name, double flops, double bytes, hipStream_t stream) : s(stream) {
+    ProfScope(const char* name, double flops, double bytes, hipStream_t stream, double exec_flops = -1.0) : s(stream) {
         if (!g_prof) return;
         ProfRecord r;
-        r.name = name; r.flops = flops; r.bytes = bytes;
+        r.name = name; r.flops = flops; r.bytes = bytes; r.exec_flops = exec_flops < 0.0 ? flops : exec_flops;
         if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
         (void)hipEventRecord(r.e0, s);
         e1 = r.e1;

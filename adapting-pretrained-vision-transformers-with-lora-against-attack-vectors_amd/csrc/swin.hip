@@ -1423,8 +1423,18 @@ static int swin_backward(vl_swin* m, float* grad_x, hipStream_t s) {
     return VL_OK;
 }
 
+// the pinned host word kernels write: 1 = bad label (k_ce_loss), 2 = an fp16-mode gradient left its range / is NaN (LayerNorm
+// and merge backward, the PGD step), like check_async of the ViT handle
 static int swin_check(vl_swin* m) {
-    if (m->err_flag && *m->err_flag) { *m->err_flag = 0; return vl_fail(VL_ERR_ARG, "a label passed to an earlier call was outside [0, num_labels)"); }
+    if (m->err_flag && *m->err_flag) {
+        const int code = *m->err_flag;
+        *m->err_flag = 0;
+        if (code == 1) return vl_fail(VL_ERR_ARG, "a label passed to an earlier call was outside [0, num_labels)");
+        if (code == 2 || code == 3)
+            return vl_fail(VL_ERR_NONFINITE, "an earlier backward pass produced a non-finite input gradient (fp16 range exceeded): "
+                                             "redo that batch with precision = f32");
+        return vl_fail(VL_ERR_HIP, "device-side error flag %d", code);
+    }
     return VL_OK;
 }
 static int swin_launch_ok(const char* what) {
@@ -1477,10 +1487,17 @@ int vl_swin_pgd_attack(vl_swin* m, const float* x0, const int64_t* labels, int b
         k_ce_loss(m->logits, m->stage_labels, batch, m->C, m->dlogits, m->loss_img, m->loss, m->err_flag, s);
         m->have_loss = 1;
         if ((rc = swin_backward(m, m->grad_img, s))) return rc;
-        k_pgd_step(m->stage_adv, m->stage_x0, m->grad_img, eps, alpha, 0.f, 1.f, n, s);
+        k_pgd_step(m->stage_adv, m->stage_x0, m->grad_img, eps, alpha, 0.f, 1.f, n, s, m->err_flag);
     }
     HIPCHK(hipMemcpyAsync(adv_out, m->stage_adv, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     return swin_launch_ok("vl_swin_pgd_attack");
+}
+
+// vl_check_errors for a Swin handle: synchronises `stream` and reports what the kernels enqueued so far flagged
+int vl_swin_check_errors(vl_swin* m, void* stream) {
+    if (!m) return vl_fail(VL_ERR_ARG, "null model");
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return vl_fail(VL_ERR_HIP, "hipStreamSynchronize failed");
+    return swin_check(m);
 }
 
 }  // extern "C"

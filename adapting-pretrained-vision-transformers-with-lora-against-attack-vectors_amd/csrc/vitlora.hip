@@ -1234,13 +1234,15 @@ int vl_profile_begin(void) {
 }
 
 // Synchronises the device, aggregates per kernel name and writes one JSON object:
-// {"name": {"n": launches, "ms": total_ms, "flops": total, "bytes": total}, ...}
+// {"name": {"n": launches, "ms": total_ms, "flops": total, "bytes": total, "exec_flops": total}, ...}
+// flops / bytes are ALGORITHMIC; exec_flops are the FLOPs the launches issue to the matrix pipes (padded rows,
+// padded attention tiles, the whole LoRA K tile) -- bench.py's roofline.path.executed_frac
 int vl_profile_report(char* buf, size_t cap) {
     if (!g_prof) return fail(VL_ERR_STATE, "profile not active");
     Profiler* p = g_prof;
     g_prof = nullptr;
     if (hipDeviceSynchronize() != hipSuccess) { delete p; return fail(VL_ERR_HIP, "hipDeviceSynchronize failed"); }
-    struct Agg { std::string name; int n; double ms, flops, bytes; };
+    struct Agg { std::string name; int n; double ms, flops, bytes, exec; };
     std::vector<Agg> agg;
     for (ProfRecord& r : p->recs) {
         float ms = 0.f;
@@ -1248,15 +1250,15 @@ int vl_profile_report(char* buf, size_t cap) {
         (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
         Agg* a = nullptr;
         for (Agg& x : agg) if (x.name == r.name) { a = &x; break; }
-        if (!a) { agg.push_back({r.name, 0, 0, 0, 0}); a = &agg.back(); }
-        a->n++; a->ms += ms; a->flops += r.flops; a->bytes += r.bytes;
+        if (!a) { agg.push_back({r.name, 0, 0, 0, 0, 0}); a = &agg.back(); }
+        a->n++; a->ms += ms; a->flops += r.flops; a->bytes += r.bytes; a->exec += r.exec_flops;
     }
     delete p;
     std::string out = "{";
     for (size_t i = 0; i < agg.size(); ++i) {
-        char line[256];
-        snprintf(line, sizeof line, "%s\"%s\": {\"n\": %d, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
-                 i ? ", " : "", agg[i].name.c_str(), agg[i].n, agg[i].ms, agg[i].flops, agg[i].bytes);
+        char line[320];
+        snprintf(line, sizeof line, "%s\"%s\": {\"n\": %d, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e, \"exec_flops\": %.6e}",
+                 i ? ", " : "", agg[i].name.c_str(), agg[i].n, agg[i].ms, agg[i].flops, agg[i].bytes, agg[i].exec);
         out += line;
     }
     out += "}";

@@ -92,10 +92,12 @@ class ViTForImageClassification(torch.nn.Module):
         return self._eng
 
     def sync_params(self):
-        """The facade heals itself: ANY torch-side write to the flat Parameter since the last forward / attack (an in-place
-        optimizer step of the reference's unmodified torch.optim.Adam, copy_, a broadcast, a kept view) bumps its version
-        counter; the library is told so and re-derives the fp16 adapter operands before it runs.  (vl_adam_step and
-        vl_param_* mark the handle themselves.)"""
+        """The facade heals itself for in-place torch operations ON THE FLAT PARAMETER ITSELF (an in-place optimizer step of
+        the reference's unmodified torch.optim.Adam, parameter.copy_/mul_/add_ under no_grad, a view taken from the Parameter):
+        those bump the Parameter's version counter; the library is told so and re-derives the fp16 adapter operands before it
+        runs.  NOT seen: writes through `parameter.data` (its own version counter) and through tensors obtained from
+        `engine.param()` / `engine.flat` -- after those call `mark_dirty()` (train_loras.py does after its broadcast of
+        `.data`).  (vl_adam_step and vl_param_* mark the handle themselves.)"""
         if self._eng is not None and self._flat_param is not None and self._flat_param._version != self._seen_version:
             self._eng.mark_dirty()
             self._seen_version = self._flat_param._version

@@ -117,3 +117,7 @@ class Adam:
         eng.adam_step(p.data, g, self.m1, self.m2, lr, self.betas[0], self.betas[1], self.eps, self.t)
         vit.mark_dirty()          # (vl_adam_step marked the handle itself: the fp16 operands are re-derived
                                   #  by the library before the next forward / attack)
+        # p.grad IS the library's flat gradient buffer and the exchange above scaled / summed it in place: it is consumed by
+        # this step (unlike torch.optim.Adam, which never writes .grad) -- a second step() without a new backward is a no-op
+        # instead of re-applying a rescaled gradient
+        p.grad = None

@@ -147,5 +147,10 @@ class SwinEngine:
                                           self._stream()), "vl_swin_pgd_attack")
         return adv
 
+    def check(self):
+        """Synchronise the current stream and raise what the kernels flagged: VitLoraError (bad label) or
+        _lib.NonFiniteGradient (fp16 mode: a gradient left the fp16 range -- redo the batch with precision="f32")."""
+        check(self.lib.vl_swin_check_errors(self.h, self._stream()), "vl_swin_check_errors")
+
 
 __all__ = ["SwinArch", "SwinEngine", "canonical_swin_key"]

@@ -276,6 +276,34 @@ def pmc_traffic(kernel):
     return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in inst) / n if n else None
 
 
+_SQ = None
+
+
+def pmc_mfma_busy(kernel):
+    """Fraction of time a SIMD's matrix pipe was busy in `kernel`, from the committed SQ counter pass
+    (profiles/pmc_sq.json, written by tools/pmc_summary.py --json: SQ_VALU_MFMA_BUSY_CYCLES / (32 shader engines x
+    SQ_BUSY_CYCLES) ... normalised per SIMD there); None when the kernel sources changed since the pass."""
+    global _SQ
+    if _SQ is None:
+        _SQ = {}
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from pmc_traffic import kernel_source_sha16
+            t = json.load(open(os.path.join(ROOT, "profiles", "pmc_sq.json")))
+            if t.get("_meta", {}).get("kernel_source_sha16") == kernel_source_sha16():
+                _SQ = {k: v for k, v in t.items() if k != "_meta"}
+        except Exception:
+            _SQ = {}
+    if not _SQ:
+        return None
+    m = re.fullmatch(r"gemm_pp_kernel<(\d+)(?:, down (\d+))?>", kernel)
+    if m:
+        kernel = f"gemm_pp_kernel<{m.group(1)}, {m.group(2) or 0}>"
+    inst = [v for k, v in _SQ.items() if k == kernel or k.split("<")[0] == kernel]
+    n = sum(v["launches"] for v in inst)
+    return round(sum(v["mfma_busy"] * v["launches"] for v in inst) / n, 4) if n else None
+
+
 T_START = time.perf_counter()
 
 
@@ -346,6 +374,9 @@ def main():
     ap.add_argument("--vitl", action="store_true", help="extras: also time the attack on ViT-L/16 + LoRA r=16 at batch 128")
     ap.add_argument("--swin", action="store_true", help="extras: also time a PGD step of the Swin-T + LoRA r=16 path (fp32) at the bench batch")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (merged-LoRA attack, LoRA train step)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --batch images PER GPU (the default, what the driver's scaling curve assumes); strong: --batch is the "
+                         "GLOBAL batch, split into contiguous shards of batch/N images per GPU (SURVEY 8e: 256 -> 32 per GPU at N = 8)")
     ap.add_argument("--precision", choices=("f16", "f32"), default="f16",
                     help="f16: fp16 operands / fp32 accumulation (the MFMA-rate path); f32: the reference's own precision (parity mode)")
     args = ap.parse_args()
@@ -390,7 +421,16 @@ def main():
         eng.param(i, t, "B").copy_(Bm)
     eng.commit()
     log("weights loaded")
-    x, y = syn.random_batch(arch, args.batch, seed=100 + rank)
+    if args.scaling == "strong":
+        # the global batch (seed 100, the one-GPU run's batch) cut into contiguous shards: rank r attacks images [lo, hi)
+        optim = importlib.import_module(PKG + ".optim")
+        lo, hi = optim.shard_batch(args.batch, rank, world)
+        xg, yg = syn.random_batch(arch, args.batch, seed=100)
+        x, y = xg[lo:hi].contiguous(), yg[lo:hi].contiguous()
+        del xg, yg
+    else:
+        x, y = syn.random_batch(arch, args.batch, seed=100 + rank)
+    local_batch = int(x.shape[0])
     x, y = x.to(dev), y.to(dev)
     adv = torch.empty_like(x)
 
@@ -417,7 +457,8 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    imgs = world * args.batch * args.steps
+    global_batch = args.batch if args.scaling == "strong" else world * args.batch
+    imgs = global_batch * args.steps
     value = imgs / dt
     if rank == 0:
         log(f"timed region: {dt:.3f} s for {args.steps} steps -> {value:.1f} img/s")
@@ -426,12 +467,13 @@ def main():
     out = {
         "metric": "adversarial images/sec (PGD-20, ViT-B/16+LoRA r=8, bs256)",
         "value": value, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": f"PGD-{args.pgd_steps} eps=8/255 alpha=2/255 random_start, ViT-B/16 (21 classes) + LoRA "
                                f"r={args.rank} on q,k,v,attn-out,fc2 ({'merged' if args.merged else 'fused'}), "
-                               f"batch {args.batch}/GPU of synthetic 224x224x3 in HBM, seeded random-init weights",
-                   "global_batch": world * args.batch, "pgd_steps": args.pgd_steps, "lora_rank": args.rank,
+                               f"batch {local_batch}/GPU of synthetic 224x224x3 in HBM, seeded random-init weights",
+                   "global_batch": global_batch, "per_gpu_batch": local_batch, "scaling": args.scaling,
+                   "pgd_steps": args.pgd_steps, "lora_rank": args.rank,
                    "parallelism": f"dp{world} (batch shards, no data-path collective)",
                    "ranks_seen_by_collective": ranks_seen,
                    "collective_backend": (dist.get_backend() if world > 1 else None)},
@@ -455,6 +497,7 @@ def main():
         log("roofline pass done")
         ps = prof.pop("pgd_step_kernel", None)
         tot_ms = sum(v["ms"] for v in prof.values())
+        exec_iter = sum(v.get("exec_flops", 0.0) for v in prof.values()) / 2      # per PGD iteration of this rank's batch
         dom = max((k for k in prof if prof[k]["flops"] > 0), key=lambda k: prof[k]["ms"])
         d = prof[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
@@ -474,6 +517,10 @@ def main():
                    "achieved": round(v["flops"] / t_s / 1e12, 1) if mf else round(v["bytes"] / t_s / 1e9, 1),
                    "unit": "TFLOP/s" if mf else "GB/s",
                    "frac": round((v["flops"] / t_s / peak) if mf else (v["bytes"] / t_s / PEAK_HBM), 4)}
+            if v.get("exec_flops", 0) > 0:
+                row["executed_gflop_per_launch"] = round(v["exec_flops"] / v["n"] / 1e9, 3)
+                row["executed_frac"] = round(v["exec_flops"] / t_s / peak, 4)
+            row["mfma_busy"] = pmc_mfma_busy(k)
             tr = pmc_traffic(k)
             row["traffic_mb_per_launch"] = None if tr is None else round(tr / 1e6, 1)
             row["traffic_over_algorithmic"] = None if (tr is None or not v["bytes"]) else round(tr / (v["bytes"] / v["n"]), 3)
@@ -485,7 +532,13 @@ def main():
             "path": {"achieved": value * args.pgd_steps * flops_img_step / 1e12, "unit": "TFLOP/s",
                      "frac": value * args.pgd_steps * flops_img_step / (world * peak),
                      "gflop_per_image_per_pgd_step": flops_img_step / 1e9,
-                     "note": "algorithmic FLOPs of the reference's computation (SURVEY 8d), not the FLOPs executed"},
+                     # what the matrix pipes were asked to do: padded rows, 32-token attention tiles, the whole LoRA K tile,
+                     # minus the dead rows of the last layer -- summed over the launches of one eager iteration, priced at the
+                     # timed region's iteration time
+                     "executed_gflop_per_image_per_pgd_step": exec_iter / local_batch / 1e9,
+                     "executed_frac": exec_iter / (1e-3 * (1e3 * dt / args.steps) / args.pgd_steps) / peak,
+                     "note": "frac: algorithmic FLOPs of the reference's computation (SURVEY 8d); executed_frac: FLOPs the kernels "
+                             "issue to the MFMA pipes (work per image differs: LoRA tile padding, T = 197 -> 224, dead rows removed)"},
             "pgd_step": None if not ps else {
                 "bound": "hbm", "achieved": ps["bytes"] / (ps["ms"] * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9,
                 "unit": "GB/s", "frac": ps["bytes"] / (ps["ms"] * 1e-3) / PEAK_HBM, "avg_launch_ms": ps["ms"] / ps["n"],
@@ -497,6 +550,30 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_extras:
         out["extras"] = extras(P, syn, arch, args, dev, x, y)
+        # the same attack at the per-GPU batches of the data-parallel configs (256 -> 32 per GPU at 8 GPUs;
+        # BASELINE config 3: 64 per GPU; the reference's own default batch is 32, train_loras.py:237-243)
+        sweep = {}
+        for bsz in (32, 64, 128):
+            if bsz >= local_batch:
+                continue
+            xs_, ys_ = x[:bsz].contiguous(), y[:bsz].contiguous()
+            advs = torch.empty_like(xs_)
+            eng.pgd_attack(xs_, ys_, EPS, ALPHA, args.pgd_steps, random_start=True, seed=1, out=advs)     # graph capture for this batch
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nrep = 3
+            for i in range(nrep):
+                eng.pgd_attack(xs_, ys_, EPS, ALPHA, args.pgd_steps, random_start=True, seed=2 + i, out=advs)
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - t0) / nrep
+            sweep[str(bsz)] = {"value": bsz / dts, "unit": "img/s", "ms_per_step": 1e3 * dts,
+                               "relative_to_headline_batch": (bsz / dts) / value}
+            log(f"extras: batch {bsz}: {bsz / dts:.1f} img/s")
+        out["extras"]["batch_sweep"] = sweep
+    if world > 1 and not args.no_extras:
+        res = dp_train_step(P, syn, arch, args, dev, rank, world)        # every rank takes part (one collective per step)
+        if rank == 0:
+            out.setdefault("extras", {})["dp_adv_lora_train_step_pgd7"] = res
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(arch, args)
@@ -506,6 +583,72 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def dp_train_step(P, syn, arch, args, dev, rank, world, bt=64, steps=4):
+    """BASELINE config 3 data-parallel (train_loras.py:308-315 made data-parallel): every rank makes PGD-7
+    adversarial examples of ITS 64 images against the current adapters, runs the LoRA train step on them, then ONE all-reduce
+    (RCCL over xGMI with backend nccl) of the flat fp32 LoRA + classifier gradient and the same fused Adam everywhere."""
+    import torch.distributed as dist
+    optim = importlib.import_module(PKG + ".optim")
+    eng = P.Engine(arch, P.LoraSpec(r=args.rank, alpha=16.0, dropout=0.1, targets=TARGETS), device=dev)
+    eng.load_state_dict(syn.random_state_dict(arch, seed=0))
+    for (i, t), (A, Bm) in syn.random_lora(arch, args.rank, TARGETS, seed=1).items():
+        eng.param(i, t, "A").copy_(A)
+        eng.param(i, t, "B").copy_(Bm)
+    eng.commit()
+    xt, yt = syn.random_batch(arch, bt, seed=300 + rank)
+    xt, yt = xt.to(dev), yt.to(dev)
+    m1, m2 = torch.zeros_like(eng.flat), torch.zeros_like(eng.flat)
+    on_gpu = dist.get_backend() == "nccl"
+    ex_ms, seen = [], 0
+
+    def one(t):
+        nonlocal seen
+        xa = eng.pgd_attack(xt, yt, EPS, ALPHA, 7, True, seed=t)
+        eng.forward(xa, normalise=True, train=True)
+        eng.loss_ce(yt)
+        _, g = eng.backward(False, True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if on_gpu:
+            optim.allreduce_weighted_mean_(g, bt, bt * world)
+            torch.cuda.synchronize()
+        else:                                   # rehearsal on one GPU (gloo): the same exchange through host memory
+            gc = g.cpu()
+            optim.allreduce_weighted_mean_(gc, bt, bt * world)
+            g.copy_(gc)
+        ex_ms.append(1e3 * (time.perf_counter() - t0))
+        eng.adam_step(eng.flat, g, m1, m2, 1e-4, 0.9, 0.999, 1e-8, t)
+        eng.commit()
+
+    for t in range(1, 3):
+        one(t)
+    ex_ms.clear()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(3, 3 + steps):
+        one(t)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = (time.perf_counter() - t0) / steps
+    # identical parameters on every rank afterwards (the exchange really averaged): max |flat - flat of rank 0|
+    ref = eng.flat.detach().clone() if on_gpu else eng.flat.detach().cpu()
+    dist.broadcast(ref, 0)
+    dev_max = float((ref.to(dev) - eng.flat).abs().max())
+    one_t = torch.ones(1, device=dev if on_gpu else "cpu")
+    dist.all_reduce(one_t)
+    seen = int(one_t.item())
+    tt = torch.tensor([dt, sum(ex_ms) / len(ex_ms), dev_max], dtype=torch.float64, device=dev if on_gpu else "cpu")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt, ex, dmax = (float(v) for v in tt.tolist())
+    return {"value": world * bt / dt, "unit": "img/s", "ms_per_step": 1e3 * dt, "batch_per_gpu": bt, "global_batch": world * bt,
+            "exchange_ms": ex, "exchange_payload_bytes": int(eng.flat.numel()) * 4, "exchange": "one in-place scale + ONE all_reduce(SUM) "
+            "of the flat fp32 LoRA + classifier gradient", "ranks_seen_by_collective": seen, "collective_backend": dist.get_backend(),
+            "max_param_divergence_across_ranks": dmax,
+            "what": "PGD-7 against the current adapters + forward(train, dropout 0.1) + CE + LoRA/classifier backward + gradient "
+                    "all-reduce + Adam on every rank (BASELINE config 3)"}
 
 
 def cpu_baseline(arch, args):

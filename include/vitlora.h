@@ -235,6 +235,8 @@ int vl_swin_loss_ce(vl_swin* m, const int64_t* labels, float* loss_out, void* st
 int vl_swin_backward_input(vl_swin* m, float* grad_x_out, void* stream);
 int vl_swin_pgd_attack(vl_swin* m, const float* x0, const int64_t* labels, int batch, float eps, float alpha, int steps,
                        int random_start, uint64_t seed, float* adv_out, void* stream);
+/* vl_check_errors for a Swin handle (same codes: VL_ERR_ARG bad label, VL_ERR_NONFINITE fp16 gradient out of range). */
+int vl_swin_check_errors(vl_swin* m, void* stream);
 
 /* Per-launch timing with HIP events on the launch stream, for bench.py's roofline object.
  * Between begin and report every kernel launch of this library is bracketed by an event

@@ -196,6 +196,55 @@ def test_lora_training_steps_match_oracle():
             assert cos > 0.97, (i, t, which, cos)
 
 
+def test_flagged_fp16_step_leaves_the_parameters_untouched_and_is_consumed_in_its_own_step():
+    """Round-3 ADVICE: flag code 2 (a backward kernel clamped a gradient to +-65504) leaves FINITE but wrong LoRA gradients;
+    the train loop therefore reads the flag with engine.check() after loss.backward() -- in the step it belongs to -- and
+    drops the step the way train_loras.py does (NaN gradient -> the fused Adam skips every element; with ranks the NaN
+    rides the one all-reduce).  Parameters and moments must be unchanged, the next evaluate() must not inherit a flag, and
+    a clean step afterwards must train."""
+    P = pkg()
+    cfg, w, lora, x, y = make_case(batch=4, layers=4)
+    gain = 512.0
+    w2 = {k: (v * gain if (k.endswith("layernorm_before.weight") or k.endswith("layernorm_after.weight")) else v) for k, v in w.items()}
+    pm = P.setup_peft_lora(_model(cfg, w2), rank=lora.r, alpha=lora.alpha, dropout=0.0)
+    eng = pm._vit._engine()
+    for (i, t), (A, B) in lora.ab.items():
+        eng.param(i, t, "A").copy_(A)
+        eng.param(i, t, "B").copy_(B)
+    pm.train()
+    crit = torch.nn.CrossEntropyLoss()
+    opt = P.Adam(pm.parameters(), lr=1e-2, model=pm)
+    xn = O.normalise(x).cuda()
+    before = pm._vit.trainable_flat().detach().clone()
+    opt.zero_grad()
+    loss = crit(pm.base_model(pixel_values=xn).logits, y.cuda())
+    loss.backward()
+    with pytest.raises(P.NonFiniteGradient):
+        eng.check()                                   # this step's flag, read in this step
+    flat = opt.params[0]
+    flat.grad = torch.full_like(flat.data, float("nan"))
+    opt.step()
+    with pytest.raises(P.NonFiniteGradient):
+        eng.check()                                   # Adam's own report (every element skipped)
+    assert torch.equal(pm._vit.trainable_flat().detach(), before)
+    assert float(opt.m1.abs().max()) == 0.0 and float(opt.m2.abs().max()) == 0.0
+    # nothing is left for the next forward (evaluate() after the last step of an epoch) to trip over
+    pm.eval()
+    with torch.no_grad():
+        pm.base_model(pixel_values=xn).logits
+    eng.check()
+    # the handle still trains: unit-gain weights through the same objects
+    pm2 = P.setup_peft_lora(_model(cfg, w), rank=lora.r, alpha=lora.alpha, dropout=0.0)
+    pm2.train()
+    opt2 = P.Adam(pm2.parameters(), lr=1e-2, model=pm2)
+    b2 = pm2._vit.trainable_flat().detach().clone()
+    crit(pm2.base_model(pixel_values=xn).logits, y.cuda()).backward()
+    pm2._vit._engine().check()
+    opt2.step()
+    assert opt2.params[0].grad is None                # the gradient buffer is consumed by step() (rewritten by the next backward)
+    assert not torch.equal(pm2._vit.trainable_flat().detach(), b2)
+
+
 def test_unmodified_torch_optimizer_is_seen_by_the_next_forward():
     """train_loras.py:284 builds torch.optim.Adam(peft_model.parameters()) -- torch writes the flat Parameter in place, the
     library never sees that call.  The facade compares the Parameter's version counter before every forward / attack and

@@ -263,6 +263,21 @@ def test_bench_contract_one_and_two_ranks():
         js = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         assert len(js) == 1, r.stdout[-500:]
         lines[tag] = json.loads(js[0])
+    # what north_star names at N > 1: strong scaling (the GLOBAL batch split into contiguous shards) and BASELINE
+    # config 3's data-parallel step -- PGD-7 + LoRA train step on every rank WITH the flat-gradient all-reduce
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", free_port(), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--batch", "32", "--pgd-steps", "2", "--no-cpu-baseline", "--no-roofline", "--scaling", "strong"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-1500:]
+    dp = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert dp["scaling"] == "strong" and dp["config"]["global_batch"] == 32 and dp["config"]["per_gpu_batch"] == 16 and dp["n_gpus"] == 2
+    assert abs(dp["value"] - 32 / (dp["ms_per_step"] / 1e3)) < 1e-6 * dp["value"]
+    ex = dp["extras"]["dp_adv_lora_train_step_pgd7"]
+    assert ex["ranks_seen_by_collective"] == 2 and ex["batch_per_gpu"] == 64 and ex["global_batch"] == 128
+    assert ex["exchange_payload_bytes"] == (958464 + 768 * 21 + 21) * 4 and ex["exchange_ms"] > 0.0
+    assert ex["max_param_divergence_across_ranks"] == 0.0          # one exchange, the same fused Adam: identical adapters everywhere
+    assert ex["value"] > 0 and abs(ex["value"] - 128 / (ex["ms_per_step"] / 1e3)) < 1e-6 * ex["value"]
     assert lines["self"]["n_gpus"] == 2 and lines["self"]["config"]["ranks_seen_by_collective"] == 2
     assert lines[2]["config"]["ranks_seen_by_collective"] == 2 and lines[1]["config"]["ranks_seen_by_collective"] == 1
     kt = lines[1]["roofline"]["kernels"]

@@ -139,3 +139,41 @@ def test_swin_refuses_unsupported_shapes():
         swin.SwinEngine(swin.SwinArch(image_size=200))              # 50 x 50 tokens: not a multiple of the window
     with pytest.raises(P.VitLoraError):
         swin.SwinEngine(swin.SwinArch(heads=(4, 6, 12, 24)))        # head_dim != 32
+
+
+def test_swin_fp16_backward_out_of_range_is_flagged_as_nonfinite_not_as_a_bad_label():
+    """Round-3 ADVICE: the Swin fp16 path shares the ViT path's saturate-and-flag backward kernels, but its API mapped ANY flag
+    to "label outside [0, num_labels)".  LayerNorm gains of 512 per block cannot fit fp16 over 12 blocks: backward_input and
+    the PGD attack must report NonFiniteGradient (VL_ERR_NONFINITE) through SwinEngine.check(), the flag is cleared by reading
+    it, a bad label is still reported as VitLoraError, and the fp32 mode has the range."""
+    P = pkg()
+    m = hf_swin(10, seed=41, depths=(2, 2, 2, 2))
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "layernorm" in n and n.endswith("weight"):
+                p.mul_(512.0)
+    g = torch.Generator().manual_seed(43)
+    x = torch.rand(2, 3, 224, 224, generator=g).cuda()
+    y = torch.randint(0, 10, (2,), generator=g).cuda()
+    eng = make_engine(m, 10, depths=(2, 2, 2, 2), precision="f16")
+    eng.forward(x, normalise=True)
+    eng.loss_ce(y)
+    eng.backward_input(tuple(x.shape))
+    with pytest.raises(P.NonFiniteGradient):
+        eng.check()
+    eng.check()                                  # cleared by reading it
+    eng.pgd_attack(x, y, 8 / 255, 2 / 255, 2, random_start=False)
+    with pytest.raises(P.NonFiniteGradient):
+        eng.check()
+    # a label outside the range is still its own error
+    eng.forward(x, normalise=True)
+    eng.loss_ce(torch.tensor([3, 10], device="cuda"))
+    with pytest.raises(P.VitLoraError) as ei:
+        eng.check()
+    assert not isinstance(ei.value, P.NonFiniteGradient)
+    e32 = make_engine(m, 10, depths=(2, 2, 2, 2), precision="f32")
+    e32.forward(x, normalise=True)
+    e32.loss_ce(y)
+    g32 = e32.backward_input(tuple(x.shape))
+    e32.check()
+    assert torch.isfinite(g32).all()

@@ -4,7 +4,7 @@
 #   (MI355X_MICROARCH.md: the two TCC counters do not fit one pass; FETCH_SIZE x2 on gfx950).
 # Summaries land in gpurun_out/prof_<tag>/ ; copy what is to be judged into profiles/.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -17,7 +17,7 @@ cp $(find $OUT/ktrace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 echo "kernel stats done"
 export VITLORA_NO_GRAPH=1
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --kernel-trace -d $OUT/pmc_sq -- $PMCB > /dev/null 2> $OUT/pmc_sq.log
-python3 tools/pmc_summary.py $(find $OUT/pmc_sq -name "*results.db" | head -1) > $OUT/pmc_sq_summary.txt
+python3 tools/pmc_summary.py $(find $OUT/pmc_sq -name "*results.db" | head -1) $OUT/pmc_sq.json > $OUT/pmc_sq_summary.txt
 echo "SQ pass done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -- $PMCB > /dev/null 2> $OUT/pmc_fetch.log
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -- $PMCB > /dev/null 2> $OUT/pmc_write.log

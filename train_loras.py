@@ -173,6 +173,7 @@ def train_rank(args, D, base_model, sets, rank_r, out_dir, mean, std):
     optimizer = V.Adam(peft_model.parameters(), lr=args.lr, model=peft_model)
     res = {"train_loss": [], "train_acc": [], "val_loss": [], "val_acc": [], "val_f1": []}
     best_val_acc = 0.0
+    skipped = steps_total = 0            # fp16 telemetry: optimizer steps dropped because a gradient left the fp16 range
     train = sets["train"]
     for epoch in range(args.epochs):
         if D.rank == 0:
@@ -183,31 +184,41 @@ def train_rank(args, D, base_model, sets, rank_r, out_dir, mean, std):
         for step, (idx, n_global) in enumerate(opt.global_batch_plan(len(train), args.batch_size, D.rank, D.world,
                                                                     shuffle_seed=args.seed + 1000 * rank_r + epoch)):
             optimizer.zero_grad()
+            ok = True
             if idx:
                 x, y = train.fetch(idx)
                 x, y = x.to(D.device), y.to(D.device)
-                for attempt in (0, 1):
-                    try:
-                        xa = x
-                        if args.pgd_inner_steps > 0:
-                            # adversarial batch against the CURRENT adapters (the library commits the last Adam step itself)
-                            engine.set_normalization(mean, std)
-                            xa = engine.pgd_attack(x, y, args.epsilon, args.pgd_alpha, args.pgd_inner_steps, random_start=True,
-                                                   seed=args.seed + 7919 * epoch + step)
-                        logits = peft_model.base_model(pixel_values=xa, normalise=True).logits
-                        loss = criterion(logits, y)
-                        loss.backward()
-                        break
-                    except V.NonFiniteGradient as e:
-                        # fp16 mode: an EARLIER step's gradient left the fp16 range.  The library reports it at the next call
-                        # (no per-step host sync) and has already done what an AMP skip-step does -- the Adam kernel left every
-                        # non-finite element (parameter and moments) untouched; the flag is cleared by reading it: go on.
-                        if attempt:
-                            raise
-                        print(f"  [rank {D.rank}] an earlier step was (partly) skipped: {e}", flush=True)
-                stats += torch.stack([loss.detach() * len(idx), (logits.detach().argmax(1) == y).sum().float(),
-                                      torch.tensor(float(len(idx)), device=D.device)])
+                try:
+                    xa = x
+                    if args.pgd_inner_steps > 0:
+                        # adversarial batch against the CURRENT adapters (the library commits the last Adam step itself)
+                        engine.set_normalization(mean, std)
+                        xa = engine.pgd_attack(x, y, args.epsilon, args.pgd_alpha, args.pgd_inner_steps, random_start=True,
+                                               seed=args.seed + 7919 * epoch + step)
+                    logits = peft_model.base_model(pixel_values=xa, normalise=True).logits
+                    loss = criterion(logits, y)
+                    loss.backward()
+                    # fp16 mode: consume the out-of-range flag HERE, so that it belongs to THIS step (code 2: a backward kernel
+                    # clamped a gradient to +-65504 -- everything downstream is finite but wrong, Adam would apply it in full)
+                    engine.check()
+                except V.NonFiniteGradient as e:
+                    ok = False
+                    print(f"  [rank {D.rank}] epoch {epoch + 1} step {step}: fp16 gradient out of range, the step is dropped on every rank ({e})",
+                          flush=True)
+                if ok:
+                    stats += torch.stack([loss.detach() * len(idx), (logits.detach().argmax(1) == y).sum().float(),
+                                          torch.tensor(float(len(idx)), device=D.device)])
+            if not ok:
+                # what an AMP skip-step does, data-parallel: a NaN gradient rides the ONE all-reduce of this step to every rank
+                # and the fused Adam leaves every element (parameter and moments) untouched where its gradient is not finite
+                flat = optimizer.params[0]
+                flat.grad = torch.full_like(flat.data, float("nan"))
             optimizer.step(local_count=len(idx), global_count=n_global)
+            try:
+                engine.check()            # the Adam kernel's own flag (code 3): identical on every rank after the all-reduce
+            except V.NonFiniteGradient:
+                skipped += 1
+            steps_total += 1
         D.sum_(stats)
         res["train_loss"].append(float(stats[0] / stats[2].clamp_min(1)))
         res["train_acc"].append(float(stats[1] / stats[2].clamp_min(1)))
@@ -242,8 +253,10 @@ def train_rank(args, D, base_model, sets, rank_r, out_dir, mean, std):
     if D.rank == 0:
         print(f"Clean Test Accuracy: {clean_acc:.4f}, F1: {clean_f1:.4f}")
         print(f"Adversarial Test Accuracy: {adv_acc:.4f}, F1: {adv_f1:.4f}")
+    if D.rank == 0:
+        print(f"fp16 range: {skipped} of {steps_total} optimizer steps dropped (VL_ERR_NONFINITE events)")
     res.update({"clean_test_acc": clean_acc, "clean_test_f1": clean_f1, "adv_test_acc": adv_acc, "adv_test_f1": adv_f1,
-                "best_val_acc": best_val_acc})
+                "best_val_acc": best_val_acc, "fp16_skipped_steps": skipped, "optimizer_steps": steps_total})
     return res
 
 

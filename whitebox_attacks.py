@@ -132,6 +132,7 @@ def main(argv=None):
                 continue
             model, class_to_idx, mean, std = loaded
             fallback = {}                    # the same model in fp32, built on first need (a batch whose fp16 backward left its range)
+            tele = {"batches": 0, "redone": 0}   # fp16 telemetry: VL_ERR_NONFINITE events = batches redone in fp32 (at 1/10 the speed)
 
             def attack_batch(mdl, images, labels, batch_seed):
                 """FGSM / PGD on one batch through `mdl` (whitebox_attacks.py:157-173); raises NonFiniteGradient if flagged."""
@@ -165,9 +166,11 @@ def main(argv=None):
                     seen.extend(filenames)
                     # random start of PGD: seeded by the batch's first file name, i.e. the same noise whichever rank draws it
                     batch_seed = args.seed + zlib.crc32(filenames[0].encode()) % (1 << 20)
+                    tele["batches"] += 1
                     try:
                         out, engine = attack_batch(model, images, labels, batch_seed)
                     except V.NonFiniteGradient as e:
+                        tele["redone"] += 1
                         print(f"    fp16 gradient out of range in batch starting at {filenames[0]} ({e}); redoing it in fp32")
                         if "model" not in fallback:
                             a32 = argparse.Namespace(**dict(vars(args), precision="f32"))
@@ -191,6 +194,7 @@ def main(argv=None):
                         print(f"    {a.upper()} results saved to: {os.path.join(base_out, a)}")
                 elif rank == 0:
                     print(f"    {len(all_seen)} images per attack written under {base_out}")
+            print(f"  [rank {rank}] fp16 range: {tele['redone']} of {tele['batches']} batches redone in fp32 (VL_ERR_NONFINITE events)")
     if dist is not None:
         dist.barrier()
 
