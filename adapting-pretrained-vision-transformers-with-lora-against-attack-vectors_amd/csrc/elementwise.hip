@@ -432,8 +432,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd16_kernel(const h16* __restr
                     }
                     if (live) *(h16x8*)(xout + off + c * 8) = xr;
                 } else {
+                    // (the add happened in the o / fc2 GEMM epilogue: an out-of-range sum arrives here as inf)
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[i][k >> 2][k & 3] = h2f(xv[k]);
+                    for (int k = 0; k < 8; ++k) { v[i][k >> 2][k & 3] = h2f(xv[k]); sat |= !(fabsf(h2f(xv[k])) <= 65504.f); }
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) s += v[i][0][k] + v[i][1][k];

@@ -15,6 +15,7 @@ enum GemmEpilogue {
     EPI_STORE_F32 = 6,    // C(f32) = acc + bias
     EPI_NONE = 7,         // diagnostic: results kept live, nothing stored (timing of the main loop alone)
     EPI_DROP_ACC = 8,     // train-mode LoRA dgrad with dropout: C(h16) = (R(h16) + mask*acc) [* G(h16)]
+    EPI_RESID_H16 = 10,   // C(h16) = round16(acc + bias + R(h16)): the residual add of the 16-bit stream in the o / fc2 epilogue (round 4)
     EPI_PATCH_PGD = 9,    // EPI_PATCH_BWD's pixel gradient consumed in registers: C(f32) = adv <- clamp(x0 + clamp(adv + alpha sign(g) - x0, +-eps), lo, hi), R = x0
 };
 
@@ -62,6 +63,7 @@ static inline double gemm_algo_bytes(const GemmArgs& a, int epi, double rows) {
     if (epi == EPI_RESID_F32) out = 8.0;                // read + write fp32
     else if (epi == EPI_GELU) out = 4.0;                // gelu(z) and gelu'(z), h16 each
     else if (epi == EPI_GELU_BWD) out = 4.0;            // read the saved gelu'(z), write h16
+    else if (epi == EPI_RESID_H16) out = 4.0;           // read the stream (h16), write the stream
     else if (epi == EPI_PATCH_BWD || epi == EPI_STORE_F32) out = 4.0;
     else if (epi == EPI_PATCH_PGD) out = 12.0;           // read adv, x0; write adv
     else if (epi == EPI_NONE) out = 0.0;

@@ -189,6 +189,7 @@ int gemm_init(int device) {
     set_attr<128, EPI_RESID_F32>();
     set_attr<128, EPI_GELU>();
     set_attr<128, EPI_GELU_BWD>();
+    set_attr<128, EPI_RESID_H16>();
     set_attr<128, EPI_PATCH_FWD>();
     set_attr<128, EPI_PATCH_BWD>();
     set_attr<128, EPI_PATCH_PGD>();
@@ -251,6 +252,7 @@ void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
         case EPI_RESID_F32: launch_t<128, EPI_RESID_F32>(a, s); break;
         case EPI_GELU: launch_t<128, EPI_GELU>(a, s); break;
         case EPI_GELU_BWD: launch_t<128, EPI_GELU_BWD>(a, s); break;
+        case EPI_RESID_H16: launch_t<128, EPI_RESID_H16>(a, s); break;
         case EPI_PATCH_FWD: launch_t<128, EPI_PATCH_FWD>(a, s); break;
         case EPI_PATCH_BWD: launch_t<128, EPI_PATCH_BWD>(a, s); break;
         case EPI_PATCH_PGD: launch_t<128, EPI_PATCH_PGD>(a, s); break;

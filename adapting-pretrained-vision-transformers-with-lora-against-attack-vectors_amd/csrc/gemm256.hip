@@ -57,7 +57,7 @@ constexpr int BK = 64;
 template <int EPI>
 constexpr int epilogue_vmem_per_row() {
     return EPI == EPI_STORE_H16 ? 2 : EPI == EPI_STORE_F32 ? 4 : EPI == EPI_RESID_F32 ? 8
-         : EPI == EPI_GELU ? 4 : EPI == EPI_GELU_BWD ? 4 : 0;
+         : EPI == EPI_GELU ? 4 : EPI == EPI_GELU_BWD ? 4 : EPI == EPI_RESID_H16 ? 4 : 0;
 }
 constexpr int clamp63(int v) { return v > 63 ? 63 : v; }
 
@@ -266,8 +266,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
 #pragma unroll
             for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(p.bias + (PERM ? n0 + 4 * j : nq + 16 * j));
         }
-        if constexpr (EPI == EPI_GELU_BWD) {
-            // the saved gelu'(z) of a whole half of the wave's rows is requested before any of it is used or any
+        if constexpr (EPI == EPI_GELU_BWD || EPI == EPI_RESID_H16) {
+            // the saved gelu'(z) (RESID_H16: the residual-stream rows) of a whole half of the wave's rows is requested before any of it is used or any
             // result is stored (the stores may alias as far as the compiler knows, so it would not hoist the loads
             // itself): two memory round trips per output tile instead of eight
             h16x8 rz[2 * MI][2];
@@ -283,7 +283,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
                 f32x4 v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = acc[i][j] + bv[j];
-                epilogue_gelu_bwd16(p, m, n0, v, rz[i][0], rz[i][1]);
+                if constexpr (EPI == EPI_GELU_BWD) epilogue_gelu_bwd16(p, m, n0, v, rz[i][0], rz[i][1]);
+                else epilogue_resid16(p, m, n0, v, rz[i][0], rz[i][1]);
             }
         } else {
 #pragma unroll
@@ -435,7 +436,7 @@ int gemm256_init() {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
         g_num_cus = prop.multiProcessorCount;
     if (g_num_cus <= 0) g_num_cus = 256;
-    set_attr<EPI_STORE_H16>(); set_attr<EPI_RESID_F32>(); set_attr<EPI_GELU>(); set_attr<EPI_GELU_BWD>();
+    set_attr<EPI_STORE_H16>(); set_attr<EPI_RESID_F32>(); set_attr<EPI_GELU>(); set_attr<EPI_GELU_BWD>(); set_attr<EPI_RESID_H16>();
     set_attr<EPI_PATCH_FWD>(); set_attr<EPI_PATCH_BWD>(); set_attr<EPI_STORE_F32>(); set_attr<EPI_NONE>();
     return g_attr_err256;
 }
@@ -446,6 +447,7 @@ void launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
         case EPI_RESID_F32: launch_t<EPI_RESID_F32>(a, s); break;
         case EPI_GELU: launch_t<EPI_GELU>(a, s); break;
         case EPI_GELU_BWD: launch_t<EPI_GELU_BWD>(a, s); break;
+        case EPI_RESID_H16: launch_t<EPI_RESID_H16>(a, s); break;
         case EPI_PATCH_FWD: launch_t<EPI_PATCH_FWD>(a, s); break;
         case EPI_PATCH_BWD: launch_t<EPI_PATCH_BWD>(a, s); break;
         case EPI_STORE_F32: launch_t<EPI_STORE_F32>(a, s); break;

@@ -50,6 +50,12 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = f2h(v[i] * h2f(z[i]));
         *(h16x4*)((h16*)p.C + (size_t)m * p.ldc + n) = o;
+    } else if constexpr (EPI == EPI_RESID_H16) {
+        const h16x4 r = *(const h16x4*)((const h16*)p.R + (size_t)m * p.ldr + n);
+        h16x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = f2h(v[i] + h2f(r[i]));
+        *(h16x4*)((h16*)p.C + (size_t)m * p.ldc + n) = o;
     } else if constexpr (EPI == EPI_DROP_ACC) {
         // d(input) = R + mask * (u (sA)) [* gelu'(z)]: the LoRA branch saw the dropped input
         const h16x4 r = *(const h16x4*)((const h16*)p.R + (size_t)m * p.ldr + n);
@@ -119,6 +125,21 @@ __device__ __forceinline__ void epilogue_gelu_bwd16(const GemmArgs& p, int m, in
     *(h16x8*)(dst + 8) = hi;
 }
 
+// RESID_H16 on 16 columns with the stream row already in registers
+__device__ __forceinline__ void epilogue_resid16(const GemmArgs& p, int m, int n0, const f32x4 (&v)[4], h16x8 r0, h16x8 r1) {
+    h16x8 lo, hi;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        lo[k] = f2h(v[0][k] + h2f(r0[k]));
+        lo[4 + k] = f2h(v[1][k] + h2f(r0[4 + k]));
+        hi[k] = f2h(v[2][k] + h2f(r1[k]));
+        hi[4 + k] = f2h(v[3][k] + h2f(r1[4 + k]));
+    }
+    h16* dst = (h16*)p.C + (size_t)m * p.ldc + n0;
+    *(h16x8*)dst = lo;
+    *(h16x8*)(dst + 8) = hi;
+}
+
 // 16 consecutive output columns n0..n0+15 of row m held by one lane as v[0..3] (the 256-row
 // kernel permutes the W rows of its LDS image so that a lane's four column tiles are adjacent):
 // 16-byte loads / stores, 64 B (h16) or 256 B (f32) contiguous per row and lane quad.
@@ -169,6 +190,9 @@ __device__ __forceinline__ void epilogue_row16(const GemmArgs& p, int m, int n0,
         // R = gelu'(z) saved by the forward epilogue
         const h16* zs = (const h16*)p.R + (size_t)m * p.ldr + n0;
         epilogue_gelu_bwd16(p, m, n0, v, *(const h16x8*)zs, *(const h16x8*)(zs + 8));
+    } else if constexpr (EPI == EPI_RESID_H16) {
+        const h16* rs = (const h16*)p.R + (size_t)m * p.ldr + n0;
+        epilogue_resid16(p, m, n0, v, *(const h16x8*)rs, *(const h16x8*)(rs + 8));
     } else if constexpr (EPI == EPI_NONE) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) asm volatile("" ::"v"(v[q]));

@@ -87,9 +87,9 @@ __device__ __forceinline__ void wait_dep(f32x4 (&a)[4], f32x4 (&b)[4]) {
 }
 
 // VMEM instructions of one 16-row epilogue block: loads requested ahead / stores
-template <int EPI> constexpr int epi_loads() { return EPI == EPI_GELU_BWD ? 2 : 0; }
+template <int EPI> constexpr int epi_loads() { return (EPI == EPI_GELU_BWD || EPI == EPI_RESID_H16) ? 2 : 0; }
 template <int EPI> constexpr int epi_stores() {
-    return EPI == EPI_STORE_H16 ? 2 : EPI == EPI_STORE_F32 ? 4 : EPI == EPI_GELU ? 4 : EPI == EPI_GELU_BWD ? 2 : 0;
+    return EPI == EPI_STORE_H16 ? 2 : EPI == EPI_STORE_F32 ? 4 : EPI == EPI_GELU ? 4 : (EPI == EPI_GELU_BWD || EPI == EPI_RESID_H16) ? 2 : 0;
 }
 
 // ND > 0: the LoRA down projection t = A1 Ad^T (16 ND columns) is computed by the HELPER group from the same LDS stages the
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
         constexpr int c = decltype(cc)::value;
         int bn; const int bm = bm_of(tile, bn);
         const int m = bm * BM + c * 16 + fr, n0 = bn * BN + wn * 64 + fg * 16;
-        if constexpr (EPI == EPI_GELU_BWD) {
+        if constexpr (EPI == EPI_GELU_BWD || EPI == EPI_RESID_H16) {
             const h16* zs = (const h16*)p.R + (size_t)m * p.ldr + n0;
             pre[c % 3][0] = gload16(zs);
             pre[c % 3][1] = gload16(zs + 8);
@@ -269,6 +269,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
             for (int q = 0; q < 4; ++q) *(f32x4*)(dst + 16 * q) = v[q];
         } else if constexpr (EPI == EPI_GELU_BWD) {
             epilogue_gelu_bwd16(p, m, n0, v, __builtin_bit_cast(h16x8, pre[c % 3][0]), __builtin_bit_cast(h16x8, pre[c % 3][1]));
+        } else if constexpr (EPI == EPI_RESID_H16) {
+            epilogue_resid16(p, m, n0, v, __builtin_bit_cast(h16x8, pre[c % 3][0]), __builtin_bit_cast(h16x8, pre[c % 3][1]));
         } else {
             epilogue_row16<EPI>(p, m, n0, v);
         }
@@ -479,7 +481,7 @@ int gemm_pp_mode() { return g_pp_mode; }
 void gemm_pp_set_mode(int m) { g_pp_mode = m; }
 
 bool gemm_pp_fuses_down(const GemmArgs& a, int epi) {
-    if (g_pp_mode == 0 || epi != EPI_STORE_H16 || !a.down_W) return false;
+    if (g_pp_mode == 0 || !(epi == EPI_STORE_H16 || epi == EPI_RESID_H16) || !a.down_W) return false;
     if (a.down_groups < 1 || a.down_groups > 2 || a.K2 != BK || !a.W2) return false;
     return shape_ok(a);
 }
@@ -489,10 +491,10 @@ bool gemm_pp_supports(const GemmArgs& a, int epi) {
     if (a.down_W) return gemm_pp_fuses_down(a, epi);
     // epilogues that READ a second operand keep it in flight in registers across steps (explicit loads); the fp32 residual
     // form does not fit the 256-register budget next to the accumulators and stays on gemm256
-    if (!(epi == EPI_STORE_H16 || epi == EPI_GELU || epi == EPI_GELU_BWD || epi == EPI_STORE_F32 || epi == EPI_NONE)) return false;
+    if (!(epi == EPI_STORE_H16 || epi == EPI_GELU || epi == EPI_GELU_BWD || epi == EPI_STORE_F32 || epi == EPI_NONE || epi == EPI_RESID_H16)) return false;
     // measured (tools/gemm_pp_check.py, MI355X): ahead of gemm256 by 7 - 12 % on the plain 16-bit-store shapes with K <= 2304
     // (qkv forward, o / qkv dgrad), level at K = 3072, behind on the GELU epilogues (4 helper waves carry the erf VALU)
-    if (g_pp_mode == 2 && !(epi == EPI_STORE_H16 && a.K1 <= 2304)) return false;
+    if (g_pp_mode == 2 && !((epi == EPI_STORE_H16 || epi == EPI_RESID_H16) && a.K1 <= 2304)) return false;
     return shape_ok(a);
 }
 
@@ -506,18 +508,21 @@ int gemm_pp_init() {
     set_attr_pp<EPI_STORE_H16, 0>(); set_attr_pp<EPI_GELU, 0>(); set_attr_pp<EPI_GELU_BWD, 0>();
     set_attr_pp<EPI_STORE_F32, 0>(); set_attr_pp<EPI_NONE, 0>();
     set_attr_pp<EPI_STORE_H16, 1>(); set_attr_pp<EPI_STORE_H16, 2>();
+    set_attr_pp<EPI_RESID_H16, 0>(); set_attr_pp<EPI_RESID_H16, 1>(); set_attr_pp<EPI_RESID_H16, 2>();
     return g_pp_attr_err;
 }
 
 void launch_gemm_pp(const GemmArgs& a, int epi, hipStream_t s) {
     if (a.down_W) {
-        if (a.down_groups == 1) launch_pp<EPI_STORE_H16, 1>(a, s); else launch_pp<EPI_STORE_H16, 2>(a, s);
+        if (epi == EPI_RESID_H16) { if (a.down_groups == 1) launch_pp<EPI_RESID_H16, 1>(a, s); else launch_pp<EPI_RESID_H16, 2>(a, s); }
+        else if (a.down_groups == 1) launch_pp<EPI_STORE_H16, 1>(a, s); else launch_pp<EPI_STORE_H16, 2>(a, s);
         return;
     }
     switch (epi) {
         case EPI_STORE_H16: launch_pp<EPI_STORE_H16, 0>(a, s); break;
         case EPI_GELU: launch_pp<EPI_GELU, 0>(a, s); break;
         case EPI_GELU_BWD: launch_pp<EPI_GELU_BWD, 0>(a, s); break;
+        case EPI_RESID_H16: launch_pp<EPI_RESID_H16, 0>(a, s); break;
         case EPI_STORE_F32: launch_pp<EPI_STORE_F32, 0>(a, s); break;
         case EPI_NONE: launch_pp<EPI_NONE, 0>(a, s); break;
     }

@@ -107,7 +107,7 @@ struct vl_model {
     hipStream_t cap_stream = nullptr;
     int64_t n_captures = 0, n_commits = 0;
     int use_graph = 1;
-    int resid_epi = 0;    // VITLORA_RESID=epilogue: residual add in the o / fc2 GEMM epilogue (fp32 read-modify-write), for A/B runs
+    int resid_epi = 1;    // residual add of the 16-bit stream in the o / fc2 GEMM epilogue (EPI_RESID_H16); 0 (VITLORA_RESID=ln): in the LayerNorm
     int plan_batch = 0, plan_train = 0;
     int attn_img_mode = -1;   // VITLORA_ATTN_IMG: 1 / 0 force the per-image attention kernels on / off, -1 = by batch size
     int num_cus = 256;

@@ -246,7 +246,11 @@ int vl_create(const vl_config* cfg, vl_model** out) {
     m->scaling = m->r ? cfg->lora_alpha / (float)m->r : 0.f;
     const char* ng = getenv("VITLORA_NO_GRAPH");
     m->use_graph = !(ng && ng[0] == '1');
-    m->resid_epi = 0;     // (round 4: the fp32 residual read-modify-write in the GEMM epilogue went away with the fp32 stream)
+    // residual add of the 16-bit stream: 1 (default) = in the epilogue of the o / fc2 projection (EPI_RESID_H16: the stream row is
+    // read two K steps ahead and x' = round16(x + acc + bias) stored -- the LayerNorm after it then moves 4 B per element instead
+    // of 8); 0 (VITLORA_RESID=ln) = the projection stores a 16-bit delta and the LayerNorm adds it.  Same arithmetic, same rounding.
+    // 2 = o and fc2, 1 = o only (VITLORA_RESID=o), 0 = neither.
+    { const char* re = getenv("VITLORA_RESID"); m->resid_epi = !re ? 2 : !strcmp(re, "ln") ? 0 : !strcmp(re, "o") ? 1 : 2; }
     { const char* dr = getenv("VITLORA_DEAD_ROWS"); m->dead_rows = !(dr && dr[0] == '0'); }
     { const char* fp = getenv("VITLORA_FUSE_PGD"); m->fuse_pgd = !(fp && fp[0] == '0'); }
     { const char* fk = getenv("VITLORA_FUSE_DOWN_MIN_K"); if (fk) m->fuse_down_min_k = atoi(fk); }
@@ -614,6 +618,7 @@ static int forward_impl(vl_model* m, const float* x, int B, int normalise, int t
     // h16 and the LayerNorm that follows adds it to the stream while it normalises: x' = round16(x + delta), h = LN(x')
     h16* delta = w.dres_h;                         // backward scratch, idle during the forward
     int* const ef = m->err_flag;
+    const bool re = m->resid_epi >= 1, re2 = m->resid_epi >= 2;      // o projection / fc2
     // eval-mode forwards only feed logits and input gradients: the last layer runs on the CLS rows alone
     const bool cls_only = m->dead_rows && !train;
     m->cur_cls_only = 0;
@@ -622,7 +627,7 @@ static int forward_impl(vl_model* m, const float* x, int B, int normalise, int t
         GemmArgs g;
         const int n1 = fused_down_fwd(m, ly.lin[LQKV]);      // t of the qkv projection comes out of LN1
         const h16* P1 = n1 ? ly.lin[LQKV].Ad : nullptr;
-        if (l == 0) k_layernorm_fwd16(w.xs16[2 * l], w.h1[l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, ly.ln1_b, M, D, m->cfg.ln_eps, nullptr, nullptr, P1, n1, w.t[LQKV][l], s, ef);
+        if (l == 0 || re2) k_layernorm_fwd16(w.xs16[2 * l], w.h1[l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, ly.ln1_b, M, D, m->cfg.ln_eps, nullptr, nullptr, P1, n1, w.t[LQKV][l], s, ef);
         else k_layernorm_fwd16(w.xs16[2 * l - 1], w.h1[l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, ly.ln1_b, M, D, m->cfg.ln_eps, delta, w.xs16[2 * l], P1, n1, w.t[LQKV][l], s, ef);
         memset(&g, 0, sizeof g); g.C = w.qkv[l]; g.ldc = 3 * D;
         linear_fwd(m, ly.lin[LQKV], w.h1[l], w.t[LQKV][l], Mpad, g, EPI_STORE_H16, s, l * 4 + LQKV, n1 > 0);
@@ -658,16 +663,19 @@ static int forward_impl(vl_model* m, const float* x, int B, int normalise, int t
                 return fail(VL_ERR_UNSUPPORTED, "attention: T > 224");
         } else if (k_attention32_fwd(w.qkv[l], w.ctx[l], w.lse[l], B, T, m->H, D, s)) return fail(VL_ERR_UNSUPPORTED, "attention: T > 224");
         memset(&g, 0, sizeof g); g.C = delta; g.ldc = D;
-        linear_fwd(m, ly.lin[LO], w.ctx[l], w.t[LO][l], Mpad, g, EPI_STORE_H16, s, l * 4 + LO, t_o);
+        if (re) { g.C = w.xs16[2 * l + 1]; g.R = w.xs16[2 * l]; g.ldr = D; }
+        linear_fwd(m, ly.lin[LO], w.ctx[l], w.t[LO][l], Mpad, g, re ? EPI_RESID_H16 : EPI_STORE_H16, s, l * 4 + LO, t_o);
         const int n2 = fused_down_fwd(m, ly.lin[LFC1]);      // t of fc1 (r columns) comes out of LN2
         const h16* P2 = n2 ? ly.lin[LFC1].Ad : nullptr;
-        k_layernorm_fwd16(w.xs16[2 * l], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D, m->cfg.ln_eps, delta, w.xs16[2 * l + 1], P2, n2, w.t[LFC1][l], s, ef);
+        if (re) k_layernorm_fwd16(w.xs16[2 * l + 1], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D, m->cfg.ln_eps, nullptr, nullptr, P2, n2, w.t[LFC1][l], s, ef);
+        else k_layernorm_fwd16(w.xs16[2 * l], w.h2[l], w.mean[2 * l + 1], w.rstd[2 * l + 1], ly.ln2_g, ly.ln2_b, M, D, m->cfg.ln_eps, delta, w.xs16[2 * l + 1], P2, n2, w.t[LFC1][l], s, ef);
         memset(&g, 0, sizeof g); g.C = w.a[l]; g.ldc = m->MLP; g.C2 = w.z[l]; g.ldc2 = m->MLP;
         linear_fwd(m, ly.lin[LFC1], w.h2[l], w.t[LFC1][l], Mpad, g, EPI_GELU, s, l * 4 + LFC1, n2 > 0);
         memset(&g, 0, sizeof g); g.C = delta; g.ldc = D;
-        linear_fwd(m, ly.lin[LFC2], w.a[l], w.t[LFC2][l], Mpad, g, EPI_STORE_H16, s, l * 4 + LFC2);
+        if (re2) { g.C = w.xs16[2 * l + 2]; g.R = w.xs16[2 * l + 1]; g.ldr = D; }
+        linear_fwd(m, ly.lin[LFC2], w.a[l], w.t[LFC2][l], Mpad, g, re2 ? EPI_RESID_H16 : EPI_STORE_H16, s, l * 4 + LFC2);
     }
-    k_layernorm_fwd16(w.xs16[2 * L - 1], nullptr, nullptr, nullptr, nullptr, nullptr, M, D, m->cfg.ln_eps, delta, w.xs16[2 * L], nullptr, 0, nullptr, s, ef);
+    if (!re2) k_layernorm_fwd16(w.xs16[2 * L - 1], nullptr, nullptr, nullptr, nullptr, nullptr, M, D, m->cfg.ln_eps, delta, w.xs16[2 * L], nullptr, 0, nullptr, s, ef);
     k_head_fwd16(w.xs16[2 * L], B, T, D, m->C, m->cfg.ln_eps, m->lnf_g, m->lnf_b, m->flat + m->cls_w_off,
                m->flat + m->cls_b_off, w.xhat, w.xf, w.rstd_f, w.logits, s);
     m->cur_B = B; m->cur_norm = normalise; m->cur_train = train; m->have_loss = 0;
@@ -1212,11 +1220,13 @@ int vl_debug_set_cus(vl_model* m, int cus) {
 // Diagnostic switches of a handle (tests, A/B timing); every change drops the cached PGD graphs.
 //   "dead_rows" 1 (default): eval-mode forwards run the last layer on the CLS rows only; 0: every row of every layer
 //   "fuse_pgd"  1 (default): vl_pgd_attack applies the PGD step inside the patch-gradient GEMM epilogue; 0: gradient to HBM + K10
+//   "resid_epi" 1 (default): the residual add of the 16-bit stream sits in the o / fc2 GEMM epilogue; 0: in the LayerNorm after it
 //   "attn_ring" 1 (default): single-pass per-image attention backward; 0: the two-phase form (process-wide switch)
 int vl_debug_set_option(vl_model* m, const char* name, int value) {
     if (!m || !name) return fail(VL_ERR_ARG, "null argument");
     if (!strcmp(name, "dead_rows")) m->dead_rows = value ? 1 : 0;
     else if (!strcmp(name, "fuse_pgd")) m->fuse_pgd = value ? 1 : 0;
+    else if (!strcmp(name, "resid_epi")) m->resid_epi = value < 0 ? 0 : value > 2 ? 2 : value;
     else if (!strcmp(name, "attn_ring")) attention32_set_ring(value);        // process-wide
     else return fail(VL_ERR_ARG, "unknown option %s", name);
     drop_graphs(m);

@@ -151,7 +151,12 @@ def test_fp16_backward_out_of_range_is_flagged_never_silent(gain):
     _, g_ref, _ = O.loss_and_input_grad(w2, cfg, x, y, lora)
     if not flagged:
         assert torch.isfinite(gx).all()
-        assert rel_l2(gx.cpu(), g_ref) < 2 * TOL_GRAD["f16"], (gain, rel_l2(gx.cpu(), g_ref))
+        # "accurate" for a network whose gains make it ill-conditioned: within 1.5x of what 16-bit STORAGE alone costs on this
+        # network (the oracle with fp16 round trips at the kernels' storage sites; at gain 4 this 128-wide net amplifies every
+        # rounding 9x -- tools/error_budget_streams.py: 1.1e-3 -> 9.8e-3 before, 2.0e-2 with the 16-bit residual stream)
+        _, g_sim, _ = O.loss_and_input_grad(w2, cfg, x, y, lora, sim16=True)
+        bound = max(2 * TOL_GRAD["f16"], 1.5 * rel_l2(g_sim, g_ref))
+        assert rel_l2(gx.cpu(), g_ref) < bound, (gain, rel_l2(gx.cpu(), g_ref), bound)
     if gain >= 512.0:
         assert flagged, "a 512x gain per LayerNorm over 4 layers cannot fit fp16: the overflow must be reported"
         # the fp32 mode is the documented way out and has the range
@@ -411,10 +416,33 @@ def test_main_gemm_kernels_agree_bitwise(shape):
     from helpers import PKG
     lib = importlib.import_module(PKG + "._lib").load()
     M, N, K1, K2 = shape
-    for epi, name in ((0, "store_h16"), (1, "resid_f32"), (2, "gelu"), (3, "gelu_bwd"), (6, "store_f32")):
+    for epi, name in ((0, "store_h16"), (1, "resid_f32"), (2, "gelu"), (3, "gelu_bwd"), (6, "store_f32"), (10, "resid_h16")):
         for mode in (0, 1):
             d = C.c_float(-1.0)
             assert lib.vl_check_gemm(M, N, K1, K2, epi, mode, C.byref(d)) == 0, lib.vl_last_error()
             assert d.value <= (4e-3 if epi == 2 else 0.0), (name, mode, d.value)
 
 
+
+
+def test_residual_add_placement_modes_agree():
+    """The residual add of the 16-bit stream can sit in the o / fc2 GEMM epilogue (EPI_RESID_H16: x' = round16(x + acc + bias),
+    default) or in the LayerNorm that follows (x' = round16(x + round16(acc + bias)), `resid_epi` 0; 1 = o projection only).
+    All three are held to the oracle at the usual tolerances and agree with each other to fp16 rounding."""
+    cfg, w, lora, x, y = make_case(image_size=224, hidden=256, heads=4, mlp=1024, layers=2, batch=3, r=8)
+    _, g_ref, lg_ref = O.loss_and_input_grad(w, cfg, x, y, lora)
+    eng = make_engine(cfg, w, lora, precision="f16")
+    outs = []
+    for mode in (2, 1, 0):
+        eng.set_option("resid_epi", mode)
+        logits = eng.forward(x.cuda(), normalise=True).cpu()
+        eng.loss_ce(y.cuda())
+        gx, _ = eng.backward(True, False, tuple(x.shape))
+        torch.cuda.synchronize()
+        assert rel_l2(logits, lg_ref) < TOL_ACT["f16"], mode
+        assert rel_l2(gx.cpu(), g_ref) < TOL_GRAD["f16"], mode
+        outs.append((logits, gx.cpu()))
+    eng.set_option("resid_epi", 2)
+    for a, b in ((0, 1), (0, 2)):
+        assert rel_l2(outs[a][0], outs[b][0]) < 2e-3 and rel_l2(outs[a][1], outs[b][1]) < 3e-3
+    assert not torch.equal(outs[0][0], outs[2][0])       # the switch really selected another path

@@ -14,8 +14,13 @@ rows = []
 for line in out.splitlines():
     m = re.search(r"Function Name: (\S+)", line)
     if m:
-        name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", m.group(1)], capture_output=True, text=True).stdout.strip()
-        cur = {"name": re.sub(r"\(.*", "", name).replace("(anonymous namespace)::", "")}
+        name = m.group(1)
+        # light demangling of the template arguments (c++filt here predates the _Float16 mangling)
+        t = re.match(r"_ZN12_GLOBAL__N_1\d+([A-Za-z0-9_]+?_kernel)(I.*?E)?Ev", name)
+        if t:
+            args = re.findall(r"L[ib](\d+)E", t.group(2) or "")
+            name = t.group(1) + ("<" + ", ".join(args) + ">" if args else "")
+        cur = {"name": name}
         rows.append(cur)
         continue
     for key, pat in (("vgpr", r" VGPRs: (\d+)"), ("agpr", r"AGPRs: (\d+)"), ("spill", r"VGPRs Spill: (\d+)"), ("sspill", r"SGPRs Spill: (\d+)"),
