@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VITLORA_LIB") or os.path.join(_HERE, "libvitlora_hip.so")
 
 VL_T = {"q": 1, "k": 2, "v": 4, "o": 8, "fc1": 16, "fc2": 32}
-VL_PREC = {"f16": 0, "fp16": 0, "f32": 1, "fp32": 1}
+VL_PREC = {"f16": 0, "fp16": 0, "f32": 1, "fp32": 1, "bf16": 2}
 
 
 class VLConfig(C.Structure):
@@ -23,7 +23,7 @@ class VLConfig(C.Structure):
         ("num_labels", C.c_int32), ("ln_eps", C.c_float),
         ("lora_r", C.c_int32), ("lora_alpha", C.c_float), ("lora_dropout", C.c_float),
         ("lora_targets", C.c_uint32), ("lora_merged", C.c_int32),
-        ("precision", C.c_int32),          # VL_PREC_F16 = 0 (fp16 operands, fp32 accumulate), VL_PREC_F32 = 1 (parity mode)
+        ("precision", C.c_int32),          # VL_PREC_F16 = 0 (fp16 operands, fp32 accumulate), VL_PREC_F32 = 1 (parity mode), VL_PREC_BF16 = 2 (bf16 operands)
         ("reserved", C.c_int32 * 3),
     ]
 

@@ -21,6 +21,8 @@
 #include "kernels.h"
 #include "prof.h"
 
+namespace VLNS {      // vl_f16 / vl_bf16: the 16-bit path is compiled once per operand type (common.h)
+
 #ifdef VITLORA_ATTN_STAMPS   // diagnostic build only (tools/attn_stamp.hip): per-wave s_memtime stamps
 __device__ unsigned long long g_attn_stamps[8192 * 8 * 8];
 #define STAMP(k) do { if (blockIdx.x < 8192 && (threadIdx.x & 63) == 0) g_attn_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -63,7 +65,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x16 mfma32(h16x8 a, h16x8 b, f32x16 c) {
+#ifdef VL_BF16
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
 }
 // raw v_exp_f32 (no denormal-range fix-up: results below 2^-126 flush to 0, exp2(-inf) = 0)
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -1509,3 +1515,5 @@ int k_attention_img_bwd(const h16* qkv, const h16* ctx, const h16* dctx, const f
     else return -1;
     return 0;
 }
+
+}  // namespace VLNS

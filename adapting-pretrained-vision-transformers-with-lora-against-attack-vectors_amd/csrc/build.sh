@@ -1,17 +1,36 @@
 #!/bin/bash
 # Build libvitlora_hip.so for gfx950 (cross-compiles without a GPU).
+# The 16-bit operand path is compiled TWICE from the same sources: fp16 operands (namespace vl_f16, also carries the fp32 parity
+# mode, Swin-T and the handle-less entry points) and -DVL_BF16 (namespace vl_bf16); api_dispatch.cpp (generated) exports the ABI.
 set -e
 cd "$(dirname "$0")"
 OUT=../libvitlora_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 mkdir -p build
+python3 gen_dispatch.py > /dev/null
+HDRS="common.h kernels.h gemm.h prof.h model.h f32_kernels.h gemm_epi.h api_rename.h ../../include/vitlora.h"
+stale() {   # stale <object> <source>
+  [ ! -f "$1" ] && return 0
+  [ "$2" -nt "$1" ] && return 0
+  for h in $HDRS; do [ "$h" -nt "$1" ] && return 0; done
+  return 1
+}
+BOTH="gemm gemm256 gemm_pp gemm_stream elementwise attention32 cls_path lora_grad vitlora"
+ONCE="f32_kernels patch swin vitlora_f32"
 pids=()
-for f in gemm gemm256 gemm_pp gemm_stream elementwise attention32 cls_path lora_grad f32_kernels patch swin vitlora_f32 vitlora; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ kernels.h -nt build/$f.o ] || [ gemm.h -nt build/$f.o ] || [ prof.h -nt build/$f.o ] || [ model.h -nt build/$f.o ] || [ f32_kernels.h -nt build/$f.o ] || [ gemm_epi.h -nt build/$f.o ] || [ ../../include/vitlora.h -nt build/$f.o ]; then
-    hipcc $FLAGS -c $f.hip -o build/$f.o &
-    pids+=($!)
-  fi
+njobs=0
+run() { "$@" & pids+=($!); njobs=$((njobs + 1)); if [ $njobs -ge 8 ]; then wait -n || exit 1; njobs=$((njobs - 1)); fi; }
+OBJS=""
+for f in $BOTH $ONCE; do
+  OBJS="$OBJS build/$f.o"
+  if stale build/$f.o $f.hip; then run hipcc $FLAGS -c $f.hip -o build/$f.o; fi
 done
+for f in $BOTH; do
+  OBJS="$OBJS build/${f}_bf16.o"
+  if stale build/${f}_bf16.o $f.hip; then run hipcc $FLAGS -DVL_BF16 -c $f.hip -o build/${f}_bf16.o; fi
+done
+OBJS="$OBJS build/api_dispatch.o"
+if stale build/api_dispatch.o api_dispatch.cpp; then run hipcc -O2 -std=c++17 -fPIC -x c++ -c api_dispatch.cpp -o build/api_dispatch.o; fi
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT build/gemm.o build/gemm256.o build/gemm_pp.o build/gemm_stream.o build/elementwise.o build/attention32.o build/cls_path.o build/lora_grad.o build/f32_kernels.o build/patch.o build/swin.o build/vitlora_f32.o build/vitlora.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS
 echo "built $OUT"

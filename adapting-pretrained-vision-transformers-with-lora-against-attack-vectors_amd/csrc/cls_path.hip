@@ -7,6 +7,8 @@
 #include "kernels.h"
 #include "prof.h"
 
+namespace VLNS {      // vl_f16 / vl_bf16: the 16-bit path is compiled once per operand type (common.h)
+
 namespace {
 
 constexpr int HD = 64;
@@ -194,3 +196,5 @@ void k_scatter_rows(const float* src, h16* dst, int B, int D, int64_t stride, hi
     const int64_t n = (int64_t)B * (D / 4);
     hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, B, D, stride);
 }
+
+}  // namespace VLNS

@@ -3,10 +3,26 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The 16-bit operand path exists in two instantiations of the SAME sources (build.sh compiles every 16-bit file twice):
+//   default      h16 = _Float16 (fp16 operands: three more mantissa bits, per-image gradient scale for the range), namespace vl_f16
+//   -DVL_BF16    h16 = __bf16   (bf16 operands: fp32's range, no gradient-range cliff; BASELINE config 5 / north_star name it), vl_bf16
+// Both run on the same-rate MFMAs (v_mfma_f32_16x16x32_{f16,bf16} / 32x32x16), share every layout and differ only in this block.
+#ifdef VL_BF16
+#define VLNS vl_bf16
+#define VL_API(name) name##_bf16
+typedef __bf16 h16;
+#define H16_MAX 3.3895314e38f        // largest finite bf16
+#define VL_DT16 2                    // vl_debug_tensor dtype code of a 16-bit tensor
+#else
+#define VLNS vl_f16
+#define VL_API(name) name##_f16
 typedef _Float16 h16;
-typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+#define H16_MAX 65504.f
+#define VL_DT16 1
+#endif
+typedef h16 h16x8 __attribute__((ext_vector_type(8)));
+typedef h16 h16x4 __attribute__((ext_vector_type(4)));
+typedef h16 h16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -14,13 +30,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
 __device__ __forceinline__ float h2f(h16 v) { return (float)v; }
-__device__ __forceinline__ h16 f2h(float v) { return (h16)v; }   // RNE (v_cvt_pk_f16_f32); overflows to inf above 65504
+__device__ __forceinline__ h16 f2h(float v) { return (h16)v; }   // RNE (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32); overflows to inf above H16_MAX
 // saturating form for the scaled gradients of the backward elementwise kernels (HBM-bound: the clamp is free there):
 // a gradient that outgrows fp16 saturates instead of turning the whole image's gradient into inf / NaN
-__device__ __forceinline__ h16 f2h_sat(float v) { return (h16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
+__device__ __forceinline__ h16 f2h_sat(float v) { return (h16)__builtin_amdgcn_fmed3f(v, -H16_MAX, H16_MAX); }
 
 __device__ __forceinline__ f32x4 mfma16(h16x8 a, h16x8 b, f32x4 c) {
+#ifdef VL_BF16
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#else
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
+}
+// acc + a.x * b.x + a.y * b.y on the packed dot unit (v_dot2c_f32_f16 / v_dot2c_f32_bf16): no conversions
+__device__ __forceinline__ float dot2_acc(h16x2 a, h16x2 b, float acc) {
+#ifdef VL_BF16
+    return __builtin_amdgcn_fdot2_f32_bf16(a, b, acc, false);
+#else
+    return __builtin_amdgcn_fdot2(a, b, acc, false);
+#endif
 }
 
 // Transposed LDS read: within each 16-lane group, lane 4q+p supplies the address of row q,

@@ -5,6 +5,8 @@
 #include "kernels.h"
 #include "prof.h"
 
+namespace VLNS {      // vl_f16 / vl_bf16: the 16-bit path is compiled once per operand type (common.h)
+
 namespace {
 
 // ---------------------------------------------------------------------------------
@@ -72,7 +74,7 @@ __device__ __forceinline__ void lora_down_load(LoraDownP<NV, NG>& r, int nv, int
 template <int NV, int NG>
 __device__ __forceinline__ void lora_down_row(const h16x4 (&v)[NV], const LoraDownP<NV, NG>& r, int nv, int lane,
                                               h16* __restrict__ out_row) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef h16x2 h2;
     float outv = 0.f;
 #pragma unroll
     for (int gq = 0; gq < NG; ++gq) {
@@ -88,8 +90,8 @@ __device__ __forceinline__ void lora_down_row(const h16x4 (&v)[NV], const LoraDo
                 for (int j = 0; j < 8; ++j) {
                     const h16x4 p = r.p[gq][i][j];
                     const h2 plo = {p[0], p[1]}, phi = {p[2], p[3]};
-                    acc[j] = __builtin_amdgcn_fdot2(vlo, plo, acc[j], false);     // v_dot2c_f32_f16: no conversions
-                    acc[j] = __builtin_amdgcn_fdot2(vhi, phi, acc[j], false);
+                    acc[j] = dot2_acc(vlo, plo, acc[j]);     // v_dot2c_f32_f16 / _bf16: no conversions
+                    acc[j] = dot2_acc(vhi, phi, acc[j]);
                 }
             }
         }
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const h16* __restric
             for (int k = 0; k < 4; ++k) {
                 o[k] = r[k] + rstd * (g[i][k] - c1 - xh[i][k] * c2);
                 ob[k] = f2h_sat(o[k]);
-                sat |= !(fabsf(o[k]) <= 65504.f);
+                sat |= !(fabsf(o[k]) <= H16_MAX);
             }
             // dx == nullptr: nobody reads the fp32 stream below (LN1 of layer 0, which never carries a fused projection;
             // the test in the fused forms would cost them two VGPRs and with that their fourth wave per SIMD)
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_small_kernel(const h16* __r
     for (int k = 0; k < 4; ++k) {
         o[k] = r[k] + rstd * (g[k] - c1 - xh[k] * c2);
         ob[k] = f2h_sat(o[k]);
-        sat |= !(fabsf(o[k]) <= 65504.f);
+        sat |= !(fabsf(o[k]) <= H16_MAX);
     }
     if (dx) *(f32x4*)(dx + (int64_t)row * D + li * 4) = o;
     *(h16x4*)(dx_h + (int64_t)row * ldh + li * 4) = ob;
@@ -347,11 +349,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_small_kernel(const h16* __r
 // LDS (in registers it would cost this layout 96 VGPRs per group), blocks walk the rows grid-stride.
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ float dot8(h16x8 a, h16x8 b, float acc) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const h2 x = {a[2 * k], a[2 * k + 1]}, y = {b[2 * k], b[2 * k + 1]};
-        acc = __builtin_amdgcn_fdot2(x, y, acc, false);
+        const h16x2 x = {a[2 * k], a[2 * k + 1]}, y = {b[2 * k], b[2 * k + 1]};
+        acc = dot2_acc(x, y, acc);
     }
     return acc;
 }
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd16_kernel(const h16* __restr
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         const float a = h2f(xv[k]) + h2f(dl[k]);
-                        sat |= !(fabsf(a) <= 65504.f);
+                        sat |= !(fabsf(a) <= H16_MAX);
                         xr[k] = f2h(a);
                         v[i][k >> 2][k & 3] = h2f(xr[k]);
                     }
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd16_kernel(const h16* __restr
                 } else {
                     // (the add happened in the o / fc2 GEMM epilogue: an out-of-range sum arrives here as inf)
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { v[i][k >> 2][k & 3] = h2f(xv[k]); sat |= !(fabsf(h2f(xv[k])) <= 65504.f); }
+                    for (int k = 0; k < 8; ++k) { v[i][k >> 2][k & 3] = h2f(xv[k]); sat |= !(fabsf(h2f(xv[k])) <= H16_MAX); }
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) s += v[i][0][k] + v[i][1][k];
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd16_kernel(const h16* __restr
                 for (int k = 0; k < 8; ++k) {
                     const float o = h2f(rv[i][k]) + rstd * (g[i][k >> 2][k & 3] - c1 - xh[i][k >> 2][k & 3] * c2);
                     ob[k] = f2h_sat(o);
-                    sat |= !(fabsf(o) <= 65504.f);
+                    sat |= !(fabsf(o) <= H16_MAX);
                 }
                 if (live) *(h16x8*)(dres + off + c * 8) = ob;
                 vb[i] = ob;                                              // the row as the next dgrad GEMM reads it
@@ -1122,3 +1123,5 @@ void k_dropout_mask(float* out, int64_t n, uint64_t seed, uint32_t stream, float
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(nblk(n, 256, 4096)), dim3(256), 0, s, out, n, seed, stream, p,
                        1.f / (1.f - p));
 }
+
+}  // namespace VLNS

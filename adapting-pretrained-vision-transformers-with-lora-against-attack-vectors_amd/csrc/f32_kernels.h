@@ -2,6 +2,8 @@
 #pragma once
 #include "common.h"
 
+namespace VLNS {
+
 // C[M,N] = alpha * A * op(W) + bias + R.  transA: element (m, k) of A at A[k*lda + m] (else A[m*lda + k]);
 // transW: element (n, k) of W at W[k*ldw + n] (else W[n*ldw + k]).  K, N and (when transposed) M multiples of 4,
 // every base pointer / leading dimension 16-byte aligned.  R may alias C (accumulate).
@@ -31,3 +33,5 @@ void k_patch_scatter_f32(const float* dp, float* gx, int B, int S, int P, const 
 int k_attn_fwd_f32(const float* qkv, float* ctx, float* lse, int B, int T, int H, int D, hipStream_t s);
 int k_attn_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const float* lse, float* dqkv, int B, int T, int H,
                    int D, hipStream_t s);
+
+}  // namespace VLNS

@@ -10,6 +10,8 @@
 #include "f32_kernels.h"
 #include "prof.h"
 
+namespace VLNS {      // vl_f16 / vl_bf16: the 16-bit path is compiled once per operand type (common.h)
+
 namespace {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -872,3 +874,5 @@ int k_attn_bwd_f32(const float* qkv, const float* ctx, const float* dctx, const 
     hipLaunchKernelGGL(attn_bwd_f32_kernel, dim3(B * H), dim3(256), attn_lds_bytes(T), s, qkv, ctx, dctx, lse, dqkv, T, H, D);
     return 0;
 }
+
+}  // namespace VLNS

@@ -2,6 +2,8 @@
 #pragma once
 #include "common.h"
 
+namespace VLNS {
+
 // C[M,N] = A1[M,K1] * W1[N,K1]^T + A2[M,K2] * W2[N,K2]^T  (+ epilogue)
 // Both operands are K-contiguous h16 ("NT" form); the optional second pair is the
 // rank-r LoRA update appended as extra K tiles:  [x | x A^T] * [W | s B]^T.
@@ -81,3 +83,5 @@ void gemm_pp_set_mode(int m);
 int gemm_stream_set_mode(int mode);    // bit 0: streaming kernel on, bit 1: LoRA down projection inside it; returns the old mode
 bool gemm_stream_fuses_down(const GemmArgs& a, int epi);   // gemm_stream.hip: a.down_W = [64 rows][K1] (down_ldw), W2 / K2 = 64 the LoRA K tile, A2 unused
 bool gemm_pp_fuses_down(const GemmArgs& a, int epi);   // a.down_* set: can launch_gemm run this GEMM with the down projection inside?   // per-device kernel attributes (outside any stream capture); 0 = ok
+
+}  // namespace VLNS

@@ -14,6 +14,8 @@
 #include "gemm_epi.h"
 #include "prof.h"
 
+namespace VLNS {      // vl_f16 / vl_bf16: the 16-bit path is compiled once per operand type (common.h)
+
 void launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);   // gemm256.hip
 bool gemm256_supports(const GemmArgs& a, int epi);
 int gemm256_init();
@@ -260,3 +262,5 @@ void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
         case EPI_DROP_ACC: launch_t<128, EPI_DROP_ACC>(a, s); break;
     }
 }
+
+}  // namespace VLNS

@@ -31,6 +31,8 @@
 #include "gemm_epi.h"
 #include "prof.h"
 
+namespace VLNS {      // vl_f16 / vl_bf16: the 16-bit path is compiled once per operand type (common.h)
+
 #ifdef VITLORA_GEMM_STAMPS   // diagnostic build only (tools/gemm_stamp.hip): per-wave s_memtime stamps, 4 per output tile
 __device__ unsigned long long g_gemm_stamps[256 * 8 * 16 * 4];
 #define GSTAMP(it, k) do { if (blockIdx.x < 256 && (it) < 16 && (threadIdx.x & 63) == 0) g_gemm_stamps[((blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (it)) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -454,3 +456,5 @@ void launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
         case EPI_NONE: launch_t<EPI_NONE>(a, s); break;
     }
 }
+
+}  // namespace VLNS

@@ -3,6 +3,8 @@
 #pragma once
 #include "gemm.h"
 
+namespace VLNS {
+
 // erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7): one v_rcp + one v_exp instead of the
 // branchy libm erff; the shared exp(-x^2/2) also gives the Gaussian pdf for gelu'.
 struct GeluParts { float cdf, pdf; };
@@ -201,3 +203,5 @@ __device__ __forceinline__ void epilogue_row16(const GemmArgs& p, int m, int n0,
         for (int q = 0; q < 4; ++q) epilogue_store<EPI>(p, m, n0 + 4 * q, v[q]);
     }
 }
+
+}  // namespace VLNS

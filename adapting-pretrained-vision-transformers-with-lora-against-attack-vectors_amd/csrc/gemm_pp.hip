@@ -35,6 +35,8 @@
 #include "gemm_epi.h"
 #include "prof.h"
 
+namespace VLNS {      // vl_f16 / vl_bf16: the 16-bit path is compiled once per operand type (common.h)
+
 namespace {
 
 constexpr int BM = 128;
@@ -481,7 +483,10 @@ int gemm_pp_mode() { return g_pp_mode; }
 void gemm_pp_set_mode(int m) { g_pp_mode = m; }
 
 bool gemm_pp_fuses_down(const GemmArgs& a, int epi) {
-    if (g_pp_mode == 0 || !(epi == EPI_STORE_H16 || epi == EPI_RESID_H16) || !a.down_W) return false;
+    // (the residual-add epilogue does not combine with the fused down projection: its two row operands requested ahead put
+    //  the kernel 12-15 VGPRs over its budget, and a scratch reload drains the LDS-DMA queue -- measured level with the
+    //  LayerNorm-side add, so fc2 keeps the 16-bit delta)
+    if (g_pp_mode == 0 || epi != EPI_STORE_H16 || !a.down_W) return false;
     if (a.down_groups < 1 || a.down_groups > 2 || a.K2 != BK || !a.W2) return false;
     return shape_ok(a);
 }
@@ -508,14 +513,13 @@ int gemm_pp_init() {
     set_attr_pp<EPI_STORE_H16, 0>(); set_attr_pp<EPI_GELU, 0>(); set_attr_pp<EPI_GELU_BWD, 0>();
     set_attr_pp<EPI_STORE_F32, 0>(); set_attr_pp<EPI_NONE, 0>();
     set_attr_pp<EPI_STORE_H16, 1>(); set_attr_pp<EPI_STORE_H16, 2>();
-    set_attr_pp<EPI_RESID_H16, 0>(); set_attr_pp<EPI_RESID_H16, 1>(); set_attr_pp<EPI_RESID_H16, 2>();
+    set_attr_pp<EPI_RESID_H16, 0>();
     return g_pp_attr_err;
 }
 
 void launch_gemm_pp(const GemmArgs& a, int epi, hipStream_t s) {
     if (a.down_W) {
-        if (epi == EPI_RESID_H16) { if (a.down_groups == 1) launch_pp<EPI_RESID_H16, 1>(a, s); else launch_pp<EPI_RESID_H16, 2>(a, s); }
-        else if (a.down_groups == 1) launch_pp<EPI_STORE_H16, 1>(a, s); else launch_pp<EPI_STORE_H16, 2>(a, s);
+        if (a.down_groups == 1) launch_pp<EPI_STORE_H16, 1>(a, s); else launch_pp<EPI_STORE_H16, 2>(a, s);
         return;
     }
     switch (epi) {
@@ -527,3 +531,5 @@ void launch_gemm_pp(const GemmArgs& a, int epi, hipStream_t s) {
         case EPI_NONE: launch_pp<EPI_NONE, 0>(a, s); break;
     }
 }
+
+}  // namespace VLNS

@@ -17,6 +17,8 @@
 #include "gemm_epi.h"
 #include "prof.h"
 
+namespace VLNS {      // vl_f16 / vl_bf16: the 16-bit path is compiled once per operand type (common.h)
+
 namespace {
 
 constexpr int BK = 64, BM = 128, CW = 8;      // CW compute waves (CW / 2 x 2), then 2 loader waves
@@ -388,3 +390,5 @@ void launch_gemm_stream(const GemmArgs& a, int epi, int bn, hipStream_t s) {
         default: break;
     }
 }
+
+}  // namespace VLNS

@@ -3,6 +3,8 @@
 #include "common.h"
 #include "gemm.h"
 
+namespace VLNS {
+
 // elementwise.hip
 void k_patch_gather(const float* x, h16* out, int B, int S, int P, int normalise, const float* mean,
                     const float* std, hipStream_t s);
@@ -96,3 +98,5 @@ void k_clamp(float* x, float lo, float hi, int64_t n, hipStream_t s);
 // inv_gscale: device pointer to the factor that undoes the fp16 gradient scale (element 0 is used; nullptr = 1)
 void k_lora_wgrad(const h16* L, int ldl, int ncols_l, const h16* Rm, int ldr, int ncols_r, int M, float scale,
                   float* out, int ldo, int transpose_out, const float* inv_gscale, hipStream_t s);
+
+}  // namespace VLNS

@@ -12,6 +12,8 @@
 #include "kernels.h"
 #include "prof.h"
 
+namespace VLNS {      // vl_f16 / vl_bf16: the 16-bit path is compiled once per operand type (common.h)
+
 namespace {
 
 constexpr int HD = 64;          // image row length (elements)
@@ -110,3 +112,5 @@ void k_lora_wgrad(const h16* L, int ldl, int ncl, const h16* Rm, int ldr, int nc
     else if (ncr <= 32) hipLaunchKernelGGL((lora_wgrad_mfma_kernel<2>), grid, dim3(256), 0, s, L, ldl, ncl, Rm, ldr, ncr, M, scale, out, ldo, transpose_out, inv_gscale);
     else hipLaunchKernelGGL((lora_wgrad_mfma_kernel<4>), grid, dim3(256), 0, s, L, ldl, ncl, Rm, ldr, ncr, M, scale, out, ldo, transpose_out, inv_gscale);
 }
+
+}  // namespace VLNS

@@ -107,7 +107,7 @@ struct vl_model {
     hipStream_t cap_stream = nullptr;
     int64_t n_captures = 0, n_commits = 0;
     int use_graph = 1;
-    int resid_epi = 1;    // residual add of the 16-bit stream in the o / fc2 GEMM epilogue (EPI_RESID_H16); 0 (VITLORA_RESID=ln): in the LayerNorm
+    int resid_epi = 1;    // residual add of the 16-bit stream in the GEMM epilogue (EPI_RESID_H16): 1 = attention output projection, 2 = + fc2, 0 = LayerNorm-side
     int plan_batch = 0, plan_train = 0;
     int attn_img_mode = -1;   // VITLORA_ATTN_IMG: 1 / 0 force the per-image attention kernels on / off, -1 = by batch size
     int num_cus = 256;
@@ -127,10 +127,19 @@ int vl_fail(int code, const char* fmt, ...);
         hipError_t e_ = (expr);                                                                 \
         if (e_ != hipSuccess) return vl_fail(VL_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+namespace VLNS {
 bool vl_drop_on(const vl_model* m);
 
-// fp32 parity path (vitlora_f32.hip)
+// fp32 parity path (vitlora_f32.hip): reached through the fp16 build only (vl_create_bf16 refuses VL_PREC_F32)
+#ifdef VL_BF16
+static inline size_t f32_carve(vl_model*, int, int, char*, size_t off0) { return off0; }
+static inline int f32_forward(vl_model*, const float*, int, int, int, hipStream_t) { return VL_ERR_STATE; }
+static inline int f32_backward(vl_model*, float*, float*, hipStream_t) { return VL_ERR_STATE; }
+static inline int f32_init(int) { return 0; }
+#else
 size_t f32_carve(vl_model* m, int B, int train, char* base, size_t off0);
 int f32_forward(vl_model* m, const float* x, int B, int normalise, int train, hipStream_t s);
 int f32_backward(vl_model* m, float* grad_x, float* flat_grad, hipStream_t s);
 int f32_init(int device);     // kernel attributes; 0 = ok
+#endif
+}  // namespace VLNS

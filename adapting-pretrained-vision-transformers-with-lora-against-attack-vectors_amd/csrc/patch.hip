@@ -13,6 +13,8 @@
 #include "kernels.h"
 #include "prof.h"
 
+namespace VLNS {      // vl_f16 / vl_bf16: the 16-bit path is compiled once per operand type (common.h)
+
 namespace {
 
 struct Tap { int i0, i1; float w0, w1; };
@@ -178,3 +180,5 @@ void k_clamp(float* x, float lo, float hi, int64_t n, hipStream_t s) {
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(clamp_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, s, x, lo, hi, n);
 }
+
+}  // namespace VLNS

@@ -22,6 +22,8 @@
 #include "model.h"
 #include "prof.h"
 
+namespace VLNS {      // vl_f16 / vl_bf16: the 16-bit path is compiled once per operand type (common.h)
+
 namespace {
 
 constexpr int WS = 7, WT = 49, HDIM = 32, KLD = 33;
@@ -800,6 +802,8 @@ struct SStage {
 };
 
 }  // namespace
+}  // namespace VLNS (reopened below: the handle is the global type include/vitlora.h declares)
+using namespace VLNS;
 
 struct vl_swin {
     vl_swin_config cfg;
@@ -823,6 +827,8 @@ struct vl_swin {
     int fuse_merge = 1;      // VITLORA_SWIN_FUSE_MERGE=0: separate materialise / gather / LayerNorm / pack passes around the merges
     int unpad_stages = 1;    // bit i: stage i keeps its h16 activations at their true width (VITLORA_SWIN_UNPAD; default: stage 1 only)
 };
+
+namespace VLNS {
 
 namespace {
 
@@ -1501,3 +1507,5 @@ int vl_swin_check_errors(vl_swin* m, void* stream) {
 }
 
 }  // extern "C"
+
+}  // namespace VLNS

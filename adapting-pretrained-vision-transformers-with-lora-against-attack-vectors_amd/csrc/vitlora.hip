@@ -9,14 +9,18 @@
 #include <string>
 #include <vector>
 
+#include "common.h"
+#include "api_rename.h"      // handle-taking entry points are declared and defined as vl_*_f16 / vl_*_bf16 (api_dispatch.cpp exports the ABI names)
 #include "model.h"
 #include "prof.h"
 
+// This file is compiled twice (common.h): process-wide state and the entry points without a handle exist once, in the fp16 build.
+extern std::vector<vl_model*> g_vl_models;      // live handles of BOTH builds (vl_adam_step finds the model a flat buffer belongs to)
+#ifndef VL_BF16
 Profiler* g_prof = nullptr;
-
+std::vector<vl_model*> g_vl_models;
 namespace {
 thread_local std::string g_err;
-std::vector<vl_model*> g_models;      // live handles (vl_adam_step finds the model a flat buffer belongs to)
 }
 
 int vl_fail(int code, const char* fmt, ...) {
@@ -28,11 +32,11 @@ int vl_fail(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
-
-namespace {
+#endif
 #define fail vl_fail
+#define g_models g_vl_models
 
-}  // namespace
+namespace VLNS {
 
 namespace {
 
@@ -210,8 +214,12 @@ bool vl_drop_on(const vl_model* m) { return m->cur_train && m->r && m->cfg.lora_
 
 extern "C" {
 
+#ifndef VL_BF16
 const char* vl_version(void) { return "vitlora-hip 0.2 (gfx950; fp16 operands or fp32)"; }
+#endif
+#ifndef VL_BF16
 const char* vl_last_error(void) { return g_err.c_str(); }
+#endif
 
 int vl_create(const vl_config* cfg, vl_model** out) {
     if (!cfg || !out) return fail(VL_ERR_ARG, "null argument");
@@ -226,7 +234,11 @@ int vl_create(const vl_config* cfg, vl_model** out) {
     if (cfg->lora_r < 0 || cfg->lora_r > 64) return fail(VL_ERR_UNSUPPORTED, "lora_r must be in [0,64]");
     if (cfg->num_labels <= 0) return fail(VL_ERR_ARG, "num_labels must be positive");
 
+#ifdef VL_BF16
+    if (cfg->precision != VL_PREC_BF16) return fail(VL_ERR_ARG, "precision %d reached the bf16 build", cfg->precision);
+#else
     if (cfg->precision != VL_PREC_F16 && cfg->precision != VL_PREC_F32) return fail(VL_ERR_ARG, "unknown precision %d", cfg->precision);
+#endif
     if (cfg->precision == VL_PREC_F32 && cfg->lora_targets && cfg->lora_r % 4)
         return fail(VL_ERR_UNSUPPORTED, "fp32 mode needs lora_r %% 4 == 0");
     int dev = 0;
@@ -249,8 +261,11 @@ int vl_create(const vl_config* cfg, vl_model** out) {
     // residual add of the 16-bit stream: 1 (default) = in the epilogue of the o / fc2 projection (EPI_RESID_H16: the stream row is
     // read two K steps ahead and x' = round16(x + acc + bias) stored -- the LayerNorm after it then moves 4 B per element instead
     // of 8); 0 (VITLORA_RESID=ln) = the projection stores a 16-bit delta and the LayerNorm adds it.  Same arithmetic, same rounding.
-    // 2 = o and fc2, 1 = o only (VITLORA_RESID=o), 0 = neither.
-    { const char* re = getenv("VITLORA_RESID"); m->resid_epi = !re ? 2 : !strcmp(re, "ln") ? 0 : !strcmp(re, "o") ? 1 : 2; }
+    // 1 (default) = the attention output projection only, 2 (VITLORA_RESID=both) = fc2 as well (then without the LoRA down
+    // projection inside the ping-pong GEMM), 0 (VITLORA_RESID=ln) = neither.  Measured on one box: 502.5 / 505.5 / 506.8 img/s
+    // for ln / o / both with the down projection fused (a variant that spills) -- the row read in the epilogue is as exposed as
+    // the LayerNorm pass it saves.
+    { const char* re = getenv("VITLORA_RESID"); m->resid_epi = !re ? 1 : !strcmp(re, "ln") ? 0 : !strcmp(re, "both") ? 2 : 1; }
     { const char* dr = getenv("VITLORA_DEAD_ROWS"); m->dead_rows = !(dr && dr[0] == '0'); }
     { const char* fp = getenv("VITLORA_FUSE_PGD"); m->fuse_pgd = !(fp && fp[0] == '0'); }
     { const char* fk = getenv("VITLORA_FUSE_DOWN_MIN_K"); if (fk) m->fuse_down_min_k = atoi(fk); }
@@ -875,12 +890,14 @@ int vl_set_normalization(vl_model* m, const float mean[3], const float stdv[3]) 
     return VL_OK;
 }
 
+#ifndef VL_BF16
 int vl_channel_affine(float* dst, const float* src, const float scale[3], const float shift[3], int batch, int64_t hw,
                       void* stream) {
     if (!dst || !src || !scale || !shift || batch <= 0 || hw <= 0) return fail(VL_ERR_ARG, "bad argument");
     k_channel_affine(dst, src, scale, shift, batch, hw, (hipStream_t)stream);
     return VL_OK;
 }
+#endif
 
 int vl_set_dropout_seed(vl_model* m, uint64_t seed) {
     if (!m) return fail(VL_ERR_ARG, "null model");
@@ -909,18 +926,22 @@ int vl_backward_lora(vl_model* m, float* flat_grad_out, void* stream) {
 }
 
 // ---- attacks ---------------------------------------------------------------------------------
+#ifndef VL_BF16
 int vl_pgd_step(float* adv, const float* x0, const float* grad, float eps, float alpha, float lo, float hi, int64_t n,
                 void* stream) {
     if (!adv || !x0 || !grad || n <= 0) return fail(VL_ERR_ARG, "bad argument");
     k_pgd_step(adv, x0, grad, eps, alpha, lo, hi, n, (hipStream_t)stream);
     return VL_OK;
 }
+#endif
 
+#ifndef VL_BF16
 int vl_pgd_init(float* adv, const float* x0, float eps, float lo, float hi, uint64_t seed, int64_t n, void* stream) {
     if (!adv || !x0 || n <= 0) return fail(VL_ERR_ARG, "bad argument");
     k_pgd_init(adv, x0, eps, lo, hi, seed, n, (hipStream_t)stream);
     return VL_OK;
 }
+#endif
 
 // VITLORA_GRAPH_DUMP=<file>: append the node list of a captured iteration (type, kernel name, grid, block, dynamic LDS)
 static void dump_graph(hipGraph_t graph) {
@@ -1042,6 +1063,7 @@ int vl_pgd_attack(vl_model* m, const float* x0, const int64_t* labels, int batch
     return VL_OK;
 }
 
+#ifndef VL_BF16
 int vl_adam_step(float* param, const float* grad, float* m1, float* m2, float lr, float b1, float b2, float eps, int t,
                  int64_t n, void* stream) {
     if (!param || !grad || !m1 || !m2 || n <= 0 || t <= 0) return fail(VL_ERR_ARG, "bad argument");
@@ -1051,14 +1073,18 @@ int vl_adam_step(float* param, const float* grad, float* m1, float* m2, float lr
     k_adam(param, grad, m1, m2, lr, b1, b2, eps, t, n, (hipStream_t)stream, err);
     return VL_OK;
 }
+#endif
 
+#ifndef VL_BF16
 int vl_quantize_u8(const float* images, uint8_t* out_hwc, int batch, int channels, int height, int width, void* stream) {
     if (!images || !out_hwc) return fail(VL_ERR_ARG, "null argument");
     k_quantize(images, out_hwc, batch, channels, height, width, (hipStream_t)stream);
     return VL_OK;
 }
+#endif
 
 // ---- adversarial patch (patch_attack.py: ART AdversarialPatchPyTorch) ------------------------------------
+#ifndef VL_BF16
 int vl_patch_apply(const float* images, const float* patch, const float* inv_affine, int batch, int image_size, int patch_size,
                    int patch_type, float* out, void* stream) {
     if (!images || !patch || !inv_affine || !out || out == images) return fail(VL_ERR_ARG, "bad argument");
@@ -1069,7 +1095,9 @@ int vl_patch_apply(const float* images, const float* patch, const float* inv_aff
     if (!capturing((hipStream_t)stream)) return check_launch("vl_patch_apply");
     return VL_OK;
 }
+#endif
 
+#ifndef VL_BF16
 int vl_patch_grad(const float* grad_out, const float* inv_affine, int batch, int image_size, int patch_size, int patch_type,
                   float* patch_grad, void* stream) {
     if (!grad_out || !inv_affine || !patch_grad) return fail(VL_ERR_ARG, "bad argument");
@@ -1080,14 +1108,18 @@ int vl_patch_grad(const float* grad_out, const float* inv_affine, int batch, int
     if (!capturing((hipStream_t)stream)) return check_launch("vl_patch_grad");
     return VL_OK;
 }
+#endif
 
+#ifndef VL_BF16
 int vl_clamp(float* x, float lo, float hi, int64_t n, void* stream) {
     if (!x || n <= 0 || !(lo <= hi)) return fail(VL_ERR_ARG, "bad argument");
     k_clamp(x, lo, hi, n, (hipStream_t)stream);
     return VL_OK;
 }
+#endif
 
 // ---- GEMM micro-benchmark (tools/gemm_sweep.py): random h16 operands, HIP-event timing -----
+#ifndef VL_BF16
 int vl_bench_gemm(int M, int N, int K1, int K2, int epi, int bn, int iters, float* ms_out) {
     if (M % 128 || N % 64 || K1 % 64 || K2 % 64 || iters <= 0 || !ms_out) return fail(VL_ERR_ARG, "bad argument");
     { int dev = 0; HIPCHK(hipGetDevice(&dev)); if (gemm_init(dev)) return fail(VL_ERR_HIP, "gemm_init failed"); }
@@ -1130,9 +1162,11 @@ int vl_bench_gemm(int M, int N, int K1, int K2, int epi, int bn, int iters, floa
     (void)hipFree(R); (void)hipFree(bias); (void)hipFree(Wd);
     return VL_OK;
 }
+#endif
 
 // ---- GEMM self-check (tests/test_hip_engine.py): the same random GEMM through the 128-row kernel (the oldest, simplest
 // form) and through whichever kernel launch_gemm selects for `pp_mode`; returns the largest |difference| over C (and C2) --
+#ifndef VL_BF16
 int vl_check_gemm(int M, int N, int K1, int K2, int epi, int pp_mode, float* max_diff) {
     if (M % 128 || N % 256 || K1 % 64 || K2 % 64 || !max_diff || pp_mode < 0 || pp_mode > 3) return fail(VL_ERR_ARG, "bad argument");
     const int nd = pp_mode >= 2 ? pp_mode - 1 : 0;           // fused LoRA down projection with 16 nd columns
@@ -1207,6 +1241,7 @@ int vl_check_gemm(int M, int N, int K1, int K2, int epi, int pp_mode, float* max
     *max_diff = (float)md;
     return VL_OK;
 }
+#endif
 
 // persistent-grid size of the GEMM kernels (and the batch threshold of the per-image attention form of `m`, if given):
 // experiments with two half-batch chains on disjoint halves of the chip (tools/dual_chain_probe.py)
@@ -1233,20 +1268,27 @@ int vl_debug_set_option(vl_model* m, const char* name, int value) {
     return VL_OK;
 }
 
+#ifndef VL_BF16
 int vl_debug_set_gemm_pp(int mode) { const int old = gemm_pp_mode(); gemm_pp_set_mode(mode); return old; }
+#endif
+#ifndef VL_BF16
 int vl_debug_set_gemm_stream(int mode) { return gemm_stream_set_mode(mode); }
+#endif
 
 // ---- profiling -------------------------------------------------------------------------------
+#ifndef VL_BF16
 int vl_profile_begin(void) {
     if (g_prof) return fail(VL_ERR_STATE, "profile already active");
     g_prof = new Profiler();
     return VL_OK;
 }
+#endif
 
 // Synchronises the device, aggregates per kernel name and writes one JSON object:
 // {"name": {"n": launches, "ms": total_ms, "flops": total, "bytes": total, "exec_flops": total}, ...}
 // flops / bytes are ALGORITHMIC; exec_flops are the FLOPs the launches issue to the matrix pipes (padded rows,
 // padded attention tiles, the whole LoRA K tile) -- bench.py's roofline.path.executed_frac
+#ifndef VL_BF16
 int vl_profile_report(char* buf, size_t cap) {
     if (!g_prof) return fail(VL_ERR_STATE, "profile not active");
     Profiler* p = g_prof;
@@ -1276,6 +1318,7 @@ int vl_profile_report(char* buf, size_t cap) {
     memcpy(buf, out.c_str(), out.size() + 1);
     return VL_OK;
 }
+#endif
 
 int vl_debug_counter(vl_model* m, const char* what, int64_t* value) {
     if (!m || !what || !value) return fail(VL_ERR_ARG, "null argument");
@@ -1286,7 +1329,7 @@ int vl_debug_counter(vl_model* m, const char* what, int64_t* value) {
 }
 
 int vl_debug_tensor(vl_model* m, const char* what, int layer, void** ptr, int64_t* numel, int* dtype) {
-    // dtype: 0 = f32, 1 = h16
+    // dtype: 0 = f32, 1 = fp16, 2 = bf16
     if (!m || !what || !ptr || !numel || !dtype) return fail(VL_ERR_ARG, "null argument");
     Workspace& w = m->ws;
     if (!w.max_batch) return fail(VL_ERR_STATE, "no workspace");
@@ -1299,11 +1342,11 @@ int vl_debug_tensor(vl_model* m, const char* what, int layer, void** ptr, int64_
             {"logits", w.logits, (int64_t)m->cur_B * m->C, 0}, {"dlogits", w.dlogits, (int64_t)m->cur_B * m->C, 0},
             {"gscale", w.gscale, m->cur_B, 0}, {"inv_gscale", w.inv_gscale, m->cur_B, 0}, {"loss_img", w.loss_img, m->cur_B, 0},
             {"xhat", w.xhat, (int64_t)m->cur_B * m->D, 0}, {"rstd_f", w.rstd_f, m->cur_B, 0},
-            {"dres_h", m->f32 ? nullptr : w.dres_h, Mp * m->D, 1}, {"dh", m->f32 ? nullptr : w.dh, Mp * m->D, 1},
-            {"dctx", m->f32 ? nullptr : w.dctx, Mp * m->D, 1}, {"dqkv", m->f32 ? nullptr : w.dqkv, Mp * 3 * m->D, 1},
-            {"dz", m->f32 ? nullptr : w.dz, Mp * m->MLP, 1}, {"u", m->f32 ? nullptr : w.u, Mp * 64, 1},
+            {"dres_h", m->f32 ? nullptr : w.dres_h, Mp * m->D, VL_DT16}, {"dh", m->f32 ? nullptr : w.dh, Mp * m->D, VL_DT16},
+            {"dctx", m->f32 ? nullptr : w.dctx, Mp * m->D, VL_DT16}, {"dqkv", m->f32 ? nullptr : w.dqkv, Mp * 3 * m->D, VL_DT16},
+            {"dz", m->f32 ? nullptr : w.dz, Mp * m->MLP, VL_DT16}, {"u", m->f32 ? nullptr : w.u, Mp * 64, VL_DT16},
             {"cls_x1", m->f32 ? nullptr : w.c.x1, (int64_t)m->cur_B * m->D, 0}, {"cls_x2", m->f32 ? nullptr : w.c.x2, (int64_t)m->cur_B * m->D, 0},
-            {"cls_ctx", m->f32 ? nullptr : w.c.ctx, (int64_t)m->cur_B * m->D, 1}};
+            {"cls_ctx", m->f32 ? nullptr : w.c.ctx, (int64_t)m->cur_B * m->D, VL_DT16}};
         for (auto& e : extra)
             if (!strcmp(what, e.name)) {
                 if (!e.p) return fail(VL_ERR_UNSUPPORTED, "%s: not in this precision mode", what);
@@ -1312,7 +1355,7 @@ int vl_debug_tensor(vl_model* m, const char* what, int layer, void** ptr, int64_
     }
     if (!strcmp(what, "xs")) {       // residual-stream snapshots: fp32 in the fp32 mode, h16 on the 16-bit path
         if (layer < 0 || layer > 2 * m->L) return fail(VL_ERR_ARG, "index");
-        *ptr = m->f32 ? (void*)w.xs[layer] : (void*)w.xs16[layer]; *numel = MD; *dtype = m->f32 ? 0 : 1; return VL_OK;
+        *ptr = m->f32 ? (void*)w.xs[layer] : (void*)w.xs16[layer]; *numel = MD; *dtype = m->f32 ? 0 : VL_DT16; return VL_OK;
     }
     if (layer < 0 || layer >= m->L) return fail(VL_ERR_ARG, "layer out of range");
     if (m->f32) {
@@ -1320,12 +1363,14 @@ int vl_debug_tensor(vl_model* m, const char* what, int layer, void** ptr, int64_
         if (!strcmp(what, "ctx")) { *ptr = w.f_ctx[layer]; *numel = MD; *dtype = 0; return VL_OK; }
         if (!strcmp(what, "z")) { *ptr = w.f_z[layer]; *numel = (int64_t)m->cur_B * m->T * m->MLP; *dtype = 0; return VL_OK; }
     } else {
-        if (!strcmp(what, "qkv")) { *ptr = w.qkv[layer]; *numel = 3 * MD; *dtype = 1; return VL_OK; }
-        if (!strcmp(what, "ctx")) { *ptr = w.ctx[layer]; *numel = MD; *dtype = 1; return VL_OK; }
-        if (!strcmp(what, "z")) { *ptr = w.z[layer]; *numel = (int64_t)m->cur_B * m->T * m->MLP; *dtype = 1; return VL_OK; }
+        if (!strcmp(what, "qkv")) { *ptr = w.qkv[layer]; *numel = 3 * MD; *dtype = VL_DT16; return VL_OK; }
+        if (!strcmp(what, "ctx")) { *ptr = w.ctx[layer]; *numel = MD; *dtype = VL_DT16; return VL_OK; }
+        if (!strcmp(what, "z")) { *ptr = w.z[layer]; *numel = (int64_t)m->cur_B * m->T * m->MLP; *dtype = VL_DT16; return VL_OK; }
     }
     if (!strcmp(what, "lse")) { *ptr = w.lse[layer]; *numel = (int64_t)m->cur_B * m->H * m->T; *dtype = 0; return VL_OK; }
     return fail(VL_ERR_ARG, "unknown debug tensor %s", what);
 }
 
 }  // extern "C"
+
+}  // namespace VLNS

@@ -8,6 +8,8 @@
 #include "f32_kernels.h"
 #include "model.h"
 
+namespace VLNS {      // vl_f16 / vl_bf16: the 16-bit path is compiled once per operand type (common.h)
+
 namespace {
 
 GemmF32 gm(const float* A, int lda, const float* W, int ldw, int transW, int M, int N, int K, float* C, int ldc) {
@@ -198,3 +200,5 @@ int f32_backward(vl_model* m, float* grad_x, float* flat_grad, hipStream_t s) {
     }
     return VL_OK;
 }
+
+}  // namespace VLNS

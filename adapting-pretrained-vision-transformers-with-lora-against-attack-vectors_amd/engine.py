@@ -91,8 +91,10 @@ def _view_f32(ptr: int, shape, device) -> torch.Tensor:
 
 
 class Engine:
-    """precision: "f16" (default; fp16 operands, fp32 accumulation and residual stream -- the MFMA-rate path) or
-    "f32" (every operand and activation fp32: the parity mode held to 1e-3 against the reference's CPU path)."""
+    """precision: "f16" (default; fp16 operands and 16-bit residual streams, fp32 accumulation -- the MFMA-rate path),
+    "bf16" (the same kernels instantiated on bf16: fp32's exponent range, so no gradient ever leaves it; 8 mantissa bits --
+    BASELINE config 5 / north_star name this type) or "f32" (every operand and activation fp32: the parity mode held to 1e-3
+    against the reference's CPU path)."""
 
     def __init__(self, arch: ArchConfig, lora: Optional[LoraSpec] = None, device="cuda:0", precision: str = "f16"):
         if not torch.cuda.is_available():
@@ -115,7 +117,7 @@ class Engine:
         if precision not in VL_PREC:
             raise ValueError(f"precision must be one of {sorted(VL_PREC)}")
         cfg.precision = VL_PREC[precision]
-        self.precision = "f32" if cfg.precision else "f16"
+        self.precision = {0: "f16", 1: "f32", 2: "bf16"}[cfg.precision]
         h = C.c_void_p()
         check(self.lib.vl_create(C.byref(cfg), C.byref(h)), "vl_create")
         self.h = h
@@ -354,7 +356,7 @@ class Engine:
         if dt.value == 0:
             return _view_f32(p.value, (n.value,), self.device)
         v = torch.as_tensor(_DevView(p.value, (n.value,), "<i2"), device=self.device)
-        return v.view(torch.float16)
+        return v.view(torch.bfloat16 if dt.value == 2 else torch.float16)
 
     def _check_images(self, x: torch.Tensor) -> torch.Tensor:
         S = self.arch.image_size

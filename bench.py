@@ -232,6 +232,24 @@ def extras(P, syn, arch, args, dev, x, y):
                             "what": f"the headline PGD-{args.pgd_steps} attack with precision=f32 (the reference's arithmetic)"}
         log(f"extras: fp32 mode {x.shape[0] / d32:.1f} img/s ({tf:.1f} TFLOP/s)")
         del e32, adv32
+        # and with bf16 operands (VL_PREC_BF16: the same kernels instantiated on __bf16; the type north_star / config 5 name)
+        eb = P.Engine(arch, P.LoraSpec(r=args.rank, alpha=16.0, dropout=0.0, targets=TARGETS), device=dev, precision="bf16")
+        eb.load_state_dict(syn.random_state_dict(arch, seed=0))
+        for (i, t), (A, Bm) in syn.random_lora(arch, args.rank, TARGETS, seed=1).items():
+            eb.param(i, t, "A").copy_(A)
+            eb.param(i, t, "B").copy_(Bm)
+        eb.commit()
+        advb = torch.empty_like(x)
+        eb.pgd_attack(x, y, EPS, ALPHA, args.pgd_steps, random_start=True, seed=1, out=advb)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eb.pgd_attack(x, y, EPS, ALPHA, args.pgd_steps, random_start=True, seed=2, out=advb)
+        torch.cuda.synchronize()
+        db = time.perf_counter() - t0
+        res["bf16_mode"] = {"value": x.shape[0] / db, "unit": "img/s", "ms_per_step": 1e3 * db, "batch": int(x.shape[0]), "dtype": "bf16",
+                            "what": f"the headline PGD-{args.pgd_steps} attack with precision=bf16"}
+        log(f"extras: bf16 mode {x.shape[0] / db:.1f} img/s")
+        del eb, advb
     res["lora_train_step"] = {"value": bt / dt, "unit": "img/s", "ms_per_step": 1e3 * dt, "batch": bt,
                               "what": "forward(train, dropout 0.1) + CE + LoRA/classifier backward + Adam, clean inputs"}
     log(f"extras: LoRA train step {1e3 * dt:.2f} ms at batch {bt}")
@@ -377,7 +395,7 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --batch images PER GPU (the default, what the driver's scaling curve assumes); strong: --batch is the "
                          "GLOBAL batch, split into contiguous shards of batch/N images per GPU (SURVEY 8e: 256 -> 32 per GPU at N = 8)")
-    ap.add_argument("--precision", choices=("f16", "f32"), default="f16",
+    ap.add_argument("--precision", choices=("f16", "bf16", "f32"), default="f16",
                     help="f16: fp16 operands / fp32 accumulation (the MFMA-rate path); f32: the reference's own precision (parity mode)")
     args = ap.parse_args()
 
@@ -478,7 +496,7 @@ def main():
                    "ranks_seen_by_collective": ranks_seen,
                    "collective_backend": (dist.get_backend() if world > 1 else None)},
     }
-    peak = PEAK_BF16_DENSE if args.precision == "f16" else PEAK_F32_MATRIX
+    peak = PEAK_F32_MATRIX if args.precision == "f32" else PEAK_BF16_DENSE
 
     if rank == 0 and not args.no_roofline:
         lib = eng.lib

@@ -43,6 +43,8 @@ extern "C" {
 
 #define VL_PREC_F16 0
 #define VL_PREC_F32 1
+#define VL_PREC_BF16 2     /* bf16 operands, fp32 accumulation: the same kernels as VL_PREC_F16 instantiated on __bf16 (no gradient-range
+                              cliff, 8 mantissa bits: see DESIGN.md for the error budget); BASELINE config 5 / north_star name this type */
 
 typedef struct vl_config {
     /* architecture: HF ViTConfig as built by create_vit_model, Utils.py:84-90 */

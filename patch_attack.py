@@ -56,7 +56,7 @@ def build_parser():
     p.add_argument("--synthetic", type=int, default=0, metavar="N")
     p.add_argument("--num_classes", type=int, default=21, help="only with --synthetic")
     p.add_argument("--arch", choices=sorted(syn.ARCHS), default="vit_b")
-    p.add_argument("--precision", choices=["f16", "f32"], default="f16",
+    p.add_argument("--precision", choices=["f16", "bf16", "f32"], default="f16",
                    help="f16: fp16 operands (fast); a gradient that leaves the fp16 range is never silent -- the run FAILS FAST with "
                         "NonFiniteGradient (no automatic fp32 redo here, unlike whitebox_attacks.py): rerun with --precision f32")
     p.add_argument("--lora_dir", default=None)

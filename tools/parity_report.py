@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Error report of the HIP path (both precisions) against (a) the reference's own outputs (tests/golden/*.npz:
+"""Error report of the HIP path (all three precisions: python tools/parity_report.py [f16] [bf16] [f32]) against (a) the reference's own outputs (tests/golden/*.npz:
 HF ViT logits and input gradient) and (b) the fp32 oracle on seeded cases incl. LoRA gradients.
 Run on the GPU box: python tools/parity_report.py"""
 import os
@@ -33,7 +33,8 @@ def lora_grad_errors(eng, gp, grads, cfg, lora):
 
 def main():
     torch.set_num_threads(16)
-    for prec in ("f16", "f32"):
+    precs = sys.argv[1:] or ["f16", "bf16", "f32"]
+    for prec in precs:
         for name in ("tiny17", "tiny197", "vitb"):
             cfg, w, x, y, z = load_case(name)
             eng = make_engine(cfg, w, None, precision=prec)
@@ -62,5 +63,22 @@ def main():
             del eng
 
 
+def pgd_agreement(precs):
+    """G4: the reference-driven ViT-B PGD trajectories (tests/golden/pgd_vitb.npz): pixels identical after k steps."""
+    import numpy as np
+    z = np.load(os.path.join(ROOT, "tests", "golden", "pgd_vitb.npz"))
+    cfg, w, x, y, _ = load_case("vitb")
+    for prec in precs:
+        eng = make_engine(cfg, w, None, precision=prec)
+        out = []
+        for k in [int(v) for v in z["steps"]]:
+            adv = eng.pgd_attack(x.cuda(), y.cuda(), float(z["eps"]), float(z["alpha"]), k, random_start=False).cpu()
+            same = ((adv - (x + torch.from_numpy(z[f"delta_x0_{k}"]))).abs() < 1e-6).float().mean().item()
+            out.append(f"PGD-{k} {same:.4f}")
+        print(f"[{prec}] G4 ViT-B pixels identical to the reference-driven trajectory: " + "  ".join(out), flush=True)
+        del eng
+
+
 if __name__ == "__main__":
     main()
+    pgd_agreement(sys.argv[1:] or ["f16", "bf16", "f32"])

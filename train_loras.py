@@ -59,7 +59,7 @@ def build_parser():
     p.add_argument("--synthetic", type=int, default=0, metavar="N")
     p.add_argument("--num_classes", type=int, default=21, help="only with --synthetic")
     p.add_argument("--arch", choices=sorted(syn.ARCHS), default="vit_b")
-    p.add_argument("--precision", choices=["f16", "f32"], default="f16")
+    p.add_argument("--precision", choices=["f16", "bf16", "f32"], default="f16")
     p.add_argument("--seed", type=int, default=0)
     return p
 

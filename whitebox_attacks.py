@@ -45,7 +45,7 @@ def build_parser():
     p.add_argument("--torchattacks-compat", action="store_true", help="(default behaviour; kept for round-1 command lines)")
     p.add_argument("--arch", choices=["tiny", "vit_b", "vit_l"], default="vit_b")
     p.add_argument("--tiny", action="store_true", help="same as --arch tiny")
-    p.add_argument("--precision", choices=["f16", "f32"], default="f16")
+    p.add_argument("--precision", choices=["f16", "bf16", "f32"], default="f16")
     p.add_argument("--synthetic", type=int, default=0, metavar="N")
     p.add_argument("--num_classes", type=int, default=21, help="only with --synthetic")
     p.add_argument("--lora_dir", default=None)
