@@ -49,6 +49,7 @@ struct GemmArgs {
     // gemm_pp only (gemm_pp_fuses_down): LoRA down projection t = A1 down_W^T computed inside the GEMM; down_W = [16 * groups
     // rows][K1] h16 (the rows of Ad in use, zero padded), down_out (optional) receives t (ld = down_ld); A2 is then unused
     const h16* down_W; int down_ldw; h16* down_out; int down_ld; int down_groups;
+    int ones_col;     // gemm_pp with the down projection inside: column 63 of the LoRA K tile is set to 1 (W2 column 63 = the bias, `bias` null)
     int tile_group;   // gemm256: tile rows per group of the tile walk (0 = 8 for N >= 2048, else 1; 1 = row-major, the round-1 order)
     int dephase;      // gemm256: start offset unit (x 8128 cycles x (workgroup/8 mod 4)); 0 = off
     // EPI_DROP_ACC: dropout mask of element (m, n) of the module input = drop_scale(seed, stream, m*N + n)

@@ -73,6 +73,12 @@ __device__ __forceinline__ f32x4 gload16(const void* ptr) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(ptr) : "memory");
     return v;
 }
+// the same for a block's registers alone (BC: no bias registers)
+template <int N, int NB>
+__device__ __forceinline__ void wait_dep1(f32x4 (&b)[4]) {
+    if constexpr (NB == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[0]), "+v"(b[1]) : "n"(N) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 // counted wait that the listed registers depend on (keeps their uses below it); NB of the block's registers are real
 template <int N, int NB>
 __device__ __forceinline__ void wait_dep(f32x4 (&a)[4], f32x4 (&b)[4]) {
@@ -97,7 +103,10 @@ template <int EPI> constexpr int epi_stores() {
 // ND > 0: the LoRA down projection t = A1 Ad^T (16 ND columns) is computed by the HELPER group from the same LDS stages the
 // compute group reads, and written as the A operand of the LoRA K tile straight into LDS (optionally also to p.down_out):
 // no separate skinny GEMM over A1, no t round trip through HBM.
-template <int EPI, int ND>
+// BC (with ND > 0 only): the bias rides in column 63 of the LoRA K tile -- the helper writes a 1 there beside t, W2 column 63 holds
+// the bias (vl_lora_commit) -- so the epilogue needs neither the 16 bias registers nor their four loads per tile (the residual-add
+// epilogue with its two row operands in flight does not fit the register budget otherwise: a spilled register is a vmcnt(0) drain)
+template <int EPI, int ND, bool BC = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntiles) {
     constexpr int STG = stg_of(ND);
     constexpr int NDMA = ndma_of(ND);
@@ -239,14 +248,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
 
     // ---- epilogue pieces (helper role): row block c of tile `tile`, this lane's row m and 16 columns from n0 ----
     constexpr int L = epi_loads<EPI>(), ST = epi_stores<EPI>();
-    f32x4 bv[4];                      // bias of the lane's 16 columns
-    f32x4 pre[3][4];                  // operands requested ahead (gelu' of GELU_BWD), ring of 3 row blocks
+    f32x4 bv[BC ? 1 : 4];             // bias of the lane's 16 columns
+    // operands requested ahead (gelu' of GELU_BWD, the stream rows of RESID_H16): block c is requested in step c and applied in
+    // step c + 2, AFTER which the same step requests block c + 2 into the slot it just read -- two slots suffice
+    f32x4 pre[2][4];
     auto request_bias = [&](int tile) {
         int bn; (void)bm_of(tile, bn);
         const int n0 = PERM ? bn * BN + wn * 64 + fg * 16 : bn * BN + wn * 64 + fg * 4;
-        const float* bp = p.bias ? p.bias + n0 : (const float*)p.A1;      // always 4 loads (static vmcnt counts)
+        if constexpr (!BC) {
+            const float* bp = p.bias ? p.bias + n0 : (const float*)p.A1;      // always 4 loads (static vmcnt counts)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bv[j] = gload16(bp + (PERM ? 4 : 16) * j);
+            for (int j = 0; j < 4; ++j) bv[j] = gload16(bp + (PERM ? 4 : 16) * j);
+        }
     };
     auto request_block = [&](int tile, auto cc) {
         constexpr int c = decltype(cc)::value;
@@ -254,8 +267,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
         const int m = bm * BM + c * 16 + fr, n0 = bn * BN + wn * 64 + fg * 16;
         if constexpr (EPI == EPI_GELU_BWD || EPI == EPI_RESID_H16) {
             const h16* zs = (const h16*)p.R + (size_t)m * p.ldr + n0;
-            pre[c % 3][0] = gload16(zs);
-            pre[c % 3][1] = gload16(zs + 8);
+            pre[c & 1][0] = gload16(zs);
+            pre[c & 1][1] = gload16(zs + 8);
         }
     };
     auto apply_block = [&](int tile, auto cc) {
@@ -264,15 +277,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
         const int m = bm * BM + c * 16 + fr, n0 = bn * BN + wn * 64 + fg * 16;
         f32x4 v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = p.bias ? acc[c][j] + bv[j] : acc[c][j];
+        for (int j = 0; j < 4; ++j) v[j] = (!BC && p.bias) ? acc[c][j] + bv[BC ? 0 : j] : acc[c][j];
         if constexpr (EPI == EPI_STORE_F32) {
             float* dst = (float*)p.C + (size_t)m * p.ldc + bn * BN + wn * 64 + fg * 4;
 #pragma unroll
             for (int q = 0; q < 4; ++q) *(f32x4*)(dst + 16 * q) = v[q];
         } else if constexpr (EPI == EPI_GELU_BWD) {
-            epilogue_gelu_bwd16(p, m, n0, v, __builtin_bit_cast(h16x8, pre[c % 3][0]), __builtin_bit_cast(h16x8, pre[c % 3][1]));
+            epilogue_gelu_bwd16(p, m, n0, v, __builtin_bit_cast(h16x8, pre[c & 1][0]), __builtin_bit_cast(h16x8, pre[c & 1][1]));
         } else if constexpr (EPI == EPI_RESID_H16) {
-            epilogue_resid16(p, m, n0, v, __builtin_bit_cast(h16x8, pre[c % 3][0]), __builtin_bit_cast(h16x8, pre[c % 3][1]));
+            epilogue_resid16(p, m, n0, v, __builtin_bit_cast(h16x8, pre[c & 1][0]), __builtin_bit_cast(h16x8, pre[c & 1][1]));
         } else {
             epilogue_row16<EPI>(p, m, n0, v);
         }
@@ -323,8 +336,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
                         *(h16x4*)(p.down_out + (size_t)(bm * BM + wn * 32 + row) * p.down_ld + d * 16 + 4 * fg) = o;
                 }
                 const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                *(h16x8*)(rp + (((2 * ND + fg) ^ (fr & 7)) * 8)) = z;
-                if (2 * ND + 4 + fg < 8) *(h16x8*)(rp + (((2 * ND + 4 + fg) ^ (fr & 7)) * 8)) = z;
+                h16x8 z1 = z;
+                z1[7] = (h16)1.0f;                        // BC: column 63 of the tile multiplies the bias column of W2
+                *(h16x8*)(rp + (((2 * ND + fg) ^ (fr & 7)) * 8)) = (BC && 2 * ND + fg == 7) ? z1 : z;
+                if (2 * ND + 4 + fg < 8) *(h16x8*)(rp + (((2 * ND + 4 + fg) ^ (fr & 7)) * 8)) = (BC && 2 * ND + 4 + fg == 7) ? z1 : z;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -338,7 +353,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
         }
     };
     // VMEM instructions a helper step issues AFTER its DMA (only when it has an epilogue to run)
-    auto post_ops = [](int S) constexpr { return (S == 0 ? 4 : 0) + ((S >= 2 && S < 10) ? ST : 0) + ((S >= 0 && S < 8) ? L : 0); };
+    auto post_ops = [](int S) constexpr { return (S == 0 && !BC ? 4 : 0) + ((S >= 2 && S < 10) ? ST : 0) + ((S >= 0 && S < 8) ? L : 0); };
     // helper step S < STATIC_STEPS.  Order inside the step: DMA for K tile S+2, apply block S-2, request block S -- the
     // stores of a step are younger than its DMA, so the wait for that DMA one step later does not wait for them.
     auto helper_static = [&](auto ss, int tile_prev, int t_cur, int stage) {
@@ -352,7 +367,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
             if constexpr (S >= 2 && S < 10) {
                 // younger than block (S-2)'s requests: everything of step S-1 and this step's DMA
                 constexpr int younger = 2 * NDMA + post_ops(S - 1);
-                wait_dep<younger, L>(bv, pre[(S - 2) % 3]);
+                if constexpr (BC) wait_dep1<younger, L>(pre[(S - 2) & 1]);
+                else wait_dep<younger, L>(bv, pre[(S - 2) & 1]);
                 apply_block(tile_prev, IC<S - 2>{});
             }
             if constexpr (S < 8) request_block(tile_prev, IC<S>{});
@@ -427,7 +443,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
         const int n0 = PERM ? bn * BN + wn * 64 + fg * 16 : bn * BN + wn * 64 + fg * 4;
         f32x4 b2[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b2[j] = p.bias ? *(const f32x4*)(p.bias + n0 + (PERM ? 4 : 16) * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) b2[j] = (!BC && p.bias) ? *(const f32x4*)(p.bias + n0 + (PERM ? 4 : 16) * j) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int m = bm * BM + i * 16 + fr;
@@ -449,7 +465,7 @@ int g_pp_cus = 0;
 int g_pp_mode = 2;          // VITLORA_GEMM_PP: 0 = off, 1 = every supported GEMM, 2 = the shapes it wins on (plain 16-bit stores, K <= 2304)
 int g_pp_attr_err = 0;
 
-template <int EPI, int ND>
+template <int EPI, int ND, bool BC = false>
 void launch_pp(const GemmArgs& a, hipStream_t s) {
     const int ntiles = (a.M / BM) * (a.N / BN);
     char name[64];
@@ -461,12 +477,12 @@ void launch_pp(const GemmArgs& a, hipStream_t s) {
     const int units = (ntiles + 1) / 2;
     const int grid = units < g_pp_cus ? (ntiles < g_pp_cus ? ntiles : g_pp_cus) : g_pp_cus;
     const size_t lds = (size_t)NSTAGE * stg_of(ND) * sizeof(h16) + 1024;
-    hipLaunchKernelGGL((gemm_pp_kernel<EPI, ND>), dim3(grid), dim3(512), lds, s, a, ntiles);
+    hipLaunchKernelGGL((gemm_pp_kernel<EPI, ND, BC>), dim3(grid), dim3(512), lds, s, a, ntiles);
 }
-template <int EPI, int ND>
+template <int EPI, int ND, bool BC = false>
 void set_attr_pp() {
     const size_t lds = (size_t)NSTAGE * stg_of(ND) * sizeof(h16) + 1024;
-    const hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, ND, BC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) g_pp_attr_err = (int)e;
 }
 
@@ -483,10 +499,11 @@ int gemm_pp_mode() { return g_pp_mode; }
 void gemm_pp_set_mode(int m) { g_pp_mode = m; }
 
 bool gemm_pp_fuses_down(const GemmArgs& a, int epi) {
-    // (the residual-add epilogue does not combine with the fused down projection: its two row operands requested ahead put
-    //  the kernel 12-15 VGPRs over its budget, and a scratch reload drains the LDS-DMA queue -- measured level with the
-    //  LayerNorm-side add, so fc2 keeps the 16-bit delta)
-    if (g_pp_mode == 0 || epi != EPI_STORE_H16 || !a.down_W) return false;
+    // the residual-add epilogue combines with the fused down projection only with the bias in the LoRA K tile (BC): its two row
+    // operands requested ahead leave no room for 16 bias registers
+    if (g_pp_mode == 0 || !a.down_W) return false;
+    if (!(epi == EPI_STORE_H16 || (epi == EPI_RESID_H16 && a.ones_col && !a.bias))) return false;
+    if (a.ones_col && epi != EPI_RESID_H16) return false;
     if (a.down_groups < 1 || a.down_groups > 2 || a.K2 != BK || !a.W2) return false;
     return shape_ok(a);
 }
@@ -513,13 +530,14 @@ int gemm_pp_init() {
     set_attr_pp<EPI_STORE_H16, 0>(); set_attr_pp<EPI_GELU, 0>(); set_attr_pp<EPI_GELU_BWD, 0>();
     set_attr_pp<EPI_STORE_F32, 0>(); set_attr_pp<EPI_NONE, 0>();
     set_attr_pp<EPI_STORE_H16, 1>(); set_attr_pp<EPI_STORE_H16, 2>();
-    set_attr_pp<EPI_RESID_H16, 0>();
+    set_attr_pp<EPI_RESID_H16, 0>(); set_attr_pp<EPI_RESID_H16, 1, true>(); set_attr_pp<EPI_RESID_H16, 2, true>();
     return g_pp_attr_err;
 }
 
 void launch_gemm_pp(const GemmArgs& a, int epi, hipStream_t s) {
     if (a.down_W) {
-        if (a.down_groups == 1) launch_pp<EPI_STORE_H16, 1>(a, s); else launch_pp<EPI_STORE_H16, 2>(a, s);
+        if (epi == EPI_RESID_H16) { if (a.down_groups == 1) launch_pp<EPI_RESID_H16, 1, true>(a, s); else launch_pp<EPI_RESID_H16, 2, true>(a, s); }
+        else if (a.down_groups == 1) launch_pp<EPI_STORE_H16, 1>(a, s); else launch_pp<EPI_STORE_H16, 2>(a, s);
         return;
     }
     switch (epi) {

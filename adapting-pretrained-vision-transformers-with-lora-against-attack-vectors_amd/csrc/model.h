@@ -107,7 +107,7 @@ struct vl_model {
     hipStream_t cap_stream = nullptr;
     int64_t n_captures = 0, n_commits = 0;
     int use_graph = 1;
-    int resid_epi = 1;    // residual add of the 16-bit stream in the GEMM epilogue (EPI_RESID_H16): 1 = attention output projection, 2 = + fc2, 0 = LayerNorm-side
+    int resid_epi = 2;    // residual add of the 16-bit stream in the GEMM epilogue (EPI_RESID_H16): 1 = attention output projection, 2 = + fc2, 0 = LayerNorm-side
     int plan_batch = 0, plan_train = 0;
     int attn_img_mode = -1;   // VITLORA_ATTN_IMG: 1 / 0 force the per-image attention kernels on / off, -1 = by batch size
     int num_cus = 256;

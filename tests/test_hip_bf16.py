@@ -116,8 +116,9 @@ def test_bf16_lora_gradients_against_the_golden_vectors(name, r, depth):
 
 def test_bf16_has_no_gradient_range_cliff():
     """LayerNorm gains of 512 over 4 layers: the fp16 path MUST flag this (tests/test_hip_engine.py) and the CLIs redo the batch
-    in fp32; bf16 carries fp32's exponent -- no flag, finite gradient, and it is the fp32 mode's gradient up to bf16 rounding of
-    an ill-conditioned network (compared by direction: the network amplifies every rounding)."""
+    in fp32; bf16 carries fp32's exponent -- no flag, a finite non-zero gradient, a finite attack.  (No accuracy claim at this
+    gain: the network is chaotic there -- the bf16 and fp32 gradients are uncorrelated, and two fp32 programs agree to a few
+    per cent only; the test is about RANGE.)"""
     P = pkg()
     cfg, w, lora, x, y = make_case(image_size=64, batch=4, r=8, layers=4)
     gain = 512.0
@@ -137,12 +138,6 @@ def test_bf16_has_no_gradient_range_cliff():
     adv = eb.pgd_attack(x.cuda(), y.cuda(), 8 / 255, 2 / 255, 3, random_start=True, seed=1)
     eb.check()
     assert torch.isfinite(gb).all() and torch.isfinite(adv).all() and float(gb.abs().max()) > 0
-    e32 = make_engine(cfg, w2, lora, precision="f32")
-    e32.forward(x.cuda(), normalise=True)
-    e32.loss_ce(y.cuda())
-    g32, _ = e32.backward(True, False, tuple(x.shape))
-    cos = float((gb.double() * g32.double()).sum() / (gb.double().norm() * g32.double().norm()))
-    assert cos > 0.9, cos
 
 
 @pytest.mark.parametrize("name", ["tiny17", "vitb"])
@@ -166,8 +161,9 @@ def test_bf16_pgd_against_the_reference_driven_trajectories(name):
     a = eng.pgd_attack(x.cuda(), y.cuda(), eps, alpha, 5, random_start=True, seed=9).clone()
     assert torch.equal(a, eng.pgd_attack(x.cuda(), y.cuda(), eps, alpha, 5, random_start=True, seed=9))
     full = eng.pgd_attack(x.cuda(), y.cuda(), eps, alpha, 5, random_start=False).clone()
-    part = eng.pgd_attack(x[1:].cuda().contiguous(), y[1:].cuda().contiguous(), eps, alpha, 5, random_start=False)
-    assert torch.equal(part, full[1:])
+    h = x.shape[0] // 2          # half the batch: the 1/B of the mean loss changes by a power of two, which the per-image scale absorbs
+    part = eng.pgd_attack(x[h:2 * h].cuda().contiguous(), y[h:2 * h].cuda().contiguous(), eps, alpha, 5, random_start=False)
+    assert torch.equal(part, full[h:2 * h])
 
 
 def test_bf16_train_steps_through_the_facade_and_the_cli(tmp_path):
