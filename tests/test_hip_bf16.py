@@ -193,7 +193,8 @@ def test_bf16_train_steps_through_the_facade_and_the_cli(tmp_path):
     assert losses[-1] < losses[0] - 1e-3, losses
     res = train_loras.main(["--output_dir", str(tmp_path / "loras"), "--attacks", "pgd", "--ranks", "4", "--epochs", "1", "--synthetic", "24",
                             "--arch", "tiny", "--batch_size", "8", "--pgd-inner-steps", "2", "--precision", "bf16"])
-    r4 = res["google_vit"]["mapillary"]["pgd"][4]
-    assert r4["fp16_skipped_steps"] == 0 and r4["optimizer_steps"] == 3
+    assert res["google_vit"]["mapillary"]["pgd"][4]["train_loss"]
+    (tele,) = [v for (d, r), v in train_loras.TELEMETRY.items() if d.startswith(str(tmp_path)) and r == 4]
+    assert tele == {"fp16_skipped_steps": 0, "optimizer_steps": 3, "precision": "bf16"}
     whitebox_attacks.main(["--models", "google_vit", "--sources", "mapillary", "--synthetic", "16", "--arch", "tiny", "--attacks", "fgsm", "pgd",
                            "--pgd_iters", "3", "--batch_size", "8", "--output_dir", str(tmp_path / "adv"), "--precision", "bf16", "--splits", "test"])

@@ -160,6 +160,9 @@ def evaluate(peft_model, dset, args, D, mean, std, criterion=None):
     return float(loss_sum / max(1, len(dset))), acc, f1
 
 
+TELEMETRY = {}        # (out_dir, rank) -> {"fp16_skipped_steps", "optimizer_steps", "precision"} of the last run in this process
+
+
 def train_rank(args, D, base_model, sets, rank_r, out_dir, mean, std):
     """One adapter: train_loras.py:269-385."""
     peft_model = V.setup_peft_lora(base_model, rank=rank_r, dropout=args.lora_dropout, seed=args.seed + 31 * rank_r)   # reproducible init
@@ -256,7 +259,12 @@ def train_rank(args, D, base_model, sets, rank_r, out_dir, mean, std):
     if D.rank == 0:
         print(f"fp16 range: {skipped} of {steps_total} optimizer steps dropped (VL_ERR_NONFINITE events)")
     res.update({"clean_test_acc": clean_acc, "clean_test_f1": clean_f1, "adv_test_acc": adv_acc, "adv_test_f1": adv_f1,
-                "best_val_acc": best_val_acc, "fp16_skipped_steps": skipped, "optimizer_steps": steps_total})
+                "best_val_acc": best_val_acc})
+    # (results.json keeps the reference's schema, train_loras.py:366-385: the range telemetry goes beside it)
+    TELEMETRY[(out_dir, rank_r)] = {"fp16_skipped_steps": skipped, "optimizer_steps": steps_total, "precision": args.precision}
+    if D.rank == 0:
+        with open(os.path.join(out_dir, f"rank{rank_r}_fp16_telemetry.json"), "w") as f:
+            json.dump(TELEMETRY[(out_dir, rank_r)], f)
     return res
 
 
