@@ -507,7 +507,9 @@ int vl_merge_weight(vl_model* m, int layer, uint32_t target, const float* W_in, 
 static size_t carve(vl_model* m, int B, int train, char* base) {
     Workspace& w = m->ws;
     const int D = m->D, L = m->L, MLP = m->MLP;
-    const int64_t Mpad = round_up((int64_t)B * m->T, 128), Mppad = round_up((int64_t)B * m->NP, 128);
+    // token rows are padded to a multiple of 256 on the 16-bit path (round 4): the 256-row GEMM then never needs a second, 128-row
+    // launch for a leftover half tile -- at batch 64 / 32 (SURVEY 8e's per-GPU shares) that launch was one full tile time for 3 tiles
+    const int64_t Mpad = round_up((int64_t)B * m->T, m->f32 ? 128 : 256), Mppad = round_up((int64_t)B * m->NP, 128);
     size_t off = 0;
     auto take = [&](size_t bytes) -> char* {
         char* p = base ? base + off : nullptr;
@@ -616,7 +618,7 @@ static int forward_impl(vl_model* m, const float* x, int B, int normalise, int t
     if (train && m->cfg.lora_merged) return fail(VL_ERR_STATE, "training needs lora_merged = 0");
     if (train && m->r && m->cfg.lora_dropout >= 1.f) return fail(VL_ERR_ARG, "lora_dropout must be < 1");
     const int D = m->D, L = m->L, T = m->T;
-    const int Mpad = (int)round_up((int64_t)B * T, 128), Mppad = (int)round_up((int64_t)B * m->NP, 128);
+    const int Mpad = (int)round_up((int64_t)B * T, m->f32 ? 128 : 256), Mppad = (int)round_up((int64_t)B * m->NP, 128);
     const int M = B * T;
     m->cur_M = M;
     m->cur_train = train;
@@ -740,7 +742,7 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
     Workspace& w = m->ws;
     if (!m->have_loss) return fail(VL_ERR_STATE, "backward before vl_loss_ce");
     const int B = m->cur_B, D = m->D, L = m->L, T = m->T, MLP = m->MLP, r = m->r;
-    const int Mpad = (int)round_up((int64_t)B * T, 128), Mppad = (int)round_up((int64_t)B * m->NP, 128);
+    const int Mpad = (int)round_up((int64_t)B * T, m->f32 ? 128 : 256), Mppad = (int)round_up((int64_t)B * m->NP, 128);
     const int M = B * T;
     const float sc = m->scaling;
     if (flat_grad && !m->cur_train) return fail(VL_ERR_STATE, "vl_backward_lora needs vl_forward(train=1)");
