@@ -369,8 +369,14 @@ __device__ __forceinline__ void lora_down_row16(const h16x8 (&v)[NV], const h16*
         for (int i = 0; i < NV; ++i) {
             const int c = li + i * 32;
             if (c < nc) {
+                // all eight rows' chunks requested before the first is used (the compiler otherwise keeps two LDS reads in
+                // flight and exposes a round trip per pair)
+                h16x8 pj[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = dot8(v[i], *(const h16x8*)(sP + (size_t)(gq * 8 + j) * D + c * 8), acc[j]);
+                for (int j = 0; j < 8; ++j) pj[j] = *(const h16x8*)(sP + (size_t)(gq * 8 + j) * D + c * 8);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = dot8(v[i], pj[j], acc[j]);
             }
         }
         // halving butterfly inside the half wave: 4 + 2 + 1 exchanges leave lane li with column (li >> 2) & 7, two xor steps finish
