@@ -284,8 +284,8 @@ def pmc_traffic(kernel):
         return None
     # the library's scopes name the ping-pong GEMM "gemm_pp_kernel<EPI>" / "<EPI, down N>"; rocprofv3 reports "<EPI, N>"
     m = re.fullmatch(r"gemm_pp_kernel<(\d+)(?:, down (\d+))?>", kernel)
-    if m:
-        kernel = f"gemm_pp_kernel<{m.group(1)}, {m.group(2) or 0}>"
+    if m:       # as rocprofv3 prints it: <EPI, ND, BC> (BC: the residual-add epilogue with the down projection inside)
+        kernel = f"gemm_pp_kernel<{m.group(1)}, {m.group(2) or 0}, {'true' if m.group(1) == '10' and m.group(2) else 'false'}>"
     if kernel in t:
         return t[kernel]["hbm_bytes_per_launch"]
     # scopes without template arguments (layernorm_fwd_kernel, attn_bwd_img_kernel ...): launch-weighted mean of the instances
@@ -315,8 +315,8 @@ def pmc_mfma_busy(kernel):
     if not _SQ:
         return None
     m = re.fullmatch(r"gemm_pp_kernel<(\d+)(?:, down (\d+))?>", kernel)
-    if m:
-        kernel = f"gemm_pp_kernel<{m.group(1)}, {m.group(2) or 0}>"
+    if m:       # as rocprofv3 prints it: <EPI, ND, BC> (BC: the residual-add epilogue with the down projection inside)
+        kernel = f"gemm_pp_kernel<{m.group(1)}, {m.group(2) or 0}, {'true' if m.group(1) == '10' and m.group(2) else 'false'}>"
     inst = [v for k, v in _SQ.items() if k == kernel or k.split("<")[0] == kernel]
     n = sum(v["launches"] for v in inst)
     return round(sum(v["mfma_busy"] * v["launches"] for v in inst) / n, 4) if n else None
