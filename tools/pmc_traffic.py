@@ -36,8 +36,8 @@ def per_kernel(db, counter):
         k = name.replace("(anonymous namespace)::", "").replace("void ", "")
         k = re.sub(r"\(.*$", "", k)
         k = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", k)
-    k = re.sub(r"^_ZN\d+vl_b?f16\d+_GLOBAL__N_1\d+", "", k)      # kernels of the two 16-bit builds (namespaces vl_f16 / vl_bf16)
-    k = k.replace("vl_f16::", "").replace("vl_bf16::", "")
+        k = re.sub(r"^_ZN\d+vl_b?f16\d+_GLOBAL__N_1\d+", "", k)      # kernels of the two 16-bit builds (namespaces vl_f16 / vl_bf16)
+        k = k.replace("vl_f16::", "").replace("vl_bf16::", "")
         k = re.sub(r"ILi(\d+)ELi(\d+)ELb(\d)EEEv.*$", r"<\1, \2, \3>", k)          # <int, int, bool>
         k = re.sub(r"ILi(\d+)EEEv.*$", r"<\1>", k)
         k = re.sub(r"(_kernel)E[Pv].*$", r"\1", k)
