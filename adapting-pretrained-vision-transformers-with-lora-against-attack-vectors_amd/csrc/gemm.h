@@ -77,6 +77,7 @@ static inline double gemm_algo_bytes(const GemmArgs& a, int epi, double rows) {
 void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s);
 int gemm_init(int device);
 int gemm_force_small(int v);   // 1: every GEMM on the 128-row kernel (self-check reference); returns the previous setting
+bool gemm_small_forced();      // that switch (or VITLORA_GEMM128=1) is on: no kernel may claim a fused form the 128-row kernel cannot run
 void gemm256_set_cus(int n);   // persistent grid size of the 256-row kernel (default: the device's CU count)
 void gemm_pp_set_cus(int n);
 int gemm_pp_mode();           // gemm_pp.hip: 0 = off, 1 = every supported shape, 2 = epilogue-heavy shapes only

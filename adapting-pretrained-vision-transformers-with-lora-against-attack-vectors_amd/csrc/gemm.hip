@@ -212,6 +212,7 @@ int gemm_init(int device) {
 }
 
 int gemm_force_small(int v) { const int old = g_force_small; g_force_small = v; return old; }
+bool gemm_small_forced() { return g_force_small == 1; }
 
 void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
     const double mv = a.Mvalid ? a.Mvalid : a.M;
@@ -236,6 +237,10 @@ void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
     if (g_force_small != 1 && gemm_stream_supports(a, epi, bn)) {        // tall and shallow: an HBM stream (gemm_stream.hip)
         launch_gemm_stream(a, epi, bn, s);
         return;
+    }
+    if (a.down_W || (a.K2 && !a.A2)) {       // a fused LoRA-down argument set: only gemm_pp / gemm_stream can run it (A2 is null)
+        fprintf(stderr, "vitlora: GEMM with the LoRA down projection inside reached the 128-row kernel (M %d N %d K %d)\n", a.M, a.N, a.K1);
+        abort();
     }
     snprintf(name, sizeof name, "gemm_nt_kernel<128, %d, %d>", bn == 64 ? 64 : 128, epi);
     ProfScope prof_(name, flops, gemm_algo_bytes(a, epi, mv), s, 2.0 * a.M * a.N * (a.K1 + a.K2));

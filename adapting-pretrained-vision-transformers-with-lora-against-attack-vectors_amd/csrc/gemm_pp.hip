@@ -501,7 +501,7 @@ void gemm_pp_set_mode(int m) { g_pp_mode = m; }
 bool gemm_pp_fuses_down(const GemmArgs& a, int epi) {
     // the residual-add epilogue combines with the fused down projection only with the bias in the LoRA K tile (BC): its two row
     // operands requested ahead leave no room for 16 bias registers
-    if (g_pp_mode == 0 || !a.down_W) return false;
+    if (g_pp_mode == 0 || !a.down_W || gemm_small_forced()) return false;
     if (!(epi == EPI_STORE_H16 || (epi == EPI_RESID_H16 && a.ones_col && !a.bias))) return false;
     if (a.ones_col && epi != EPI_RESID_H16) return false;
     if (a.down_groups < 1 || a.down_groups > 2 || a.K2 != BK || !a.W2) return false;

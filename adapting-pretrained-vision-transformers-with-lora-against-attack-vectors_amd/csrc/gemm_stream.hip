@@ -358,6 +358,7 @@ int gemm_stream_set_mode(int mode) {
 // a.down_W set (down_groups = 1: 64 rows, down_ldw), W2 / ldw2 / K2 = 64 the LoRA K tile, A2 unused: can the down projection
 // run inside this GEMM?
 bool gemm_stream_fuses_down(const GemmArgs& a, int epi) {
+    if (gemm_small_forced()) return false;
     if (!g_stream_on || !g_stream_down || a.a_gather || !a.down_W || a.down_out) return false;
     if (a.M < g_stream_min_rows || a.M % BM || a.K1 + a.K2 > g_stream_max_k || a.K1 % BK || a.K1 < BK || a.K2 != BK || a.N % 128) return false;
     return epi == EPI_STORE_H16 || epi == EPI_GELU_BWD;

@@ -114,6 +114,7 @@ struct vl_model {
     int dead_rows = 1;        // eval-mode forward / backward: last layer on CLS rows only (VITLORA_DEAD_ROWS=0 or vl_debug_set_dead_rows: off)
     int cur_cls_only = 0;     // the last forward took that route
     int fuse_down_min_k = 2048;   // LoRA down projection inside the ping-pong GEMM for projections at least this deep (VITLORA_FUSE_DOWN_MIN_K)
+    int small_m_rows = 16384;     // token rows up to which the "small batch" forms apply (VITLORA_SMALL_M_ROWS; batch <= 83 at T = 197)
     int fuse_pgd = 1;         // vl_pgd_attack: PGD step inside the patch-gradient epilogue (VITLORA_FUSE_PGD=0: separate K10 launch)
     int* err_flag = nullptr;                    // pinned host word written by kernels (bad label, ...), read at API entry
     float mean[3] = {0.485f, 0.456f, 0.406f};   // get_normalization, Utils.py:92-93

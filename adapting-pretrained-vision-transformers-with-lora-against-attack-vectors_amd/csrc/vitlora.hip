@@ -98,6 +98,10 @@ bool down_fusable(const vl_model* m, const Linear& ln) {
     return !m->cfg.lora_merged && !ln.slots.empty() && ln.kext == 64 && m->r <= 8;
 }
 
+// smallest K from which a LoRA down projection rides inside the ping-pong GEMM instead of a skinny launch of its own: deep
+// products at any size (VITLORA_FUSE_DOWN_MIN_K, default 2048: fc2); every supported depth (K >= 768) at small batches
+int down_min_k(const vl_model* m, int Mpad) { return Mpad <= m->small_m_rows ? 768 : m->fuse_down_min_k; }
+
 // y = x W^T (+ LoRA) with epilogue; `t` receives the LoRA down projection when fused.
 // stream_id = layer*4 + projection: names the dropout mask of this projection's LoRA branch input.
 // t_ready: the LayerNorm that produced x already wrote t (fused_down_fwd below).
@@ -121,7 +125,9 @@ void linear_fwd(vl_model* m, const Linear& ln, const h16* x, h16* t, int Mpad, G
         // long-K projections (fc2: K = 3072, t would cost a pass over the whole GELU output): the ping-pong GEMM computes t
         // itself from the A tiles it streams through LDS anyway (gemm_pp.hip, ND > 0) and still writes it out for wgrad
         bool fused = false;
-        if (!t_ready && xb == x && ln.in >= m->fuse_down_min_k && ln.kext == 64) {
+        // (the small-batch extension only with the plain store: with the residual-add epilogue the fused form takes its bias from
+        //  the LoRA K tile in fp16 -- results would then depend on the batch SIZE, and shards of a batch must reproduce it bit for bit)
+        if (!t_ready && xb == x && ln.kext == 64 && ln.in >= (epi == EPI_STORE_H16 ? down_min_k(m, Mpad) : m->fuse_down_min_k)) {
             GemmArgs f = g;
             f.down_W = ln.Ad; f.down_ldw = ln.in; f.down_out = t; f.down_ld = ln.kext;
             f.down_groups = ext_cols(m, ln) <= 16 ? 1 : ext_cols(m, ln) <= 32 ? 2 : 0;
@@ -145,6 +151,20 @@ void linear_dgrad(vl_model* m, const Linear& ln, const h16* dy, h16* u, int Mpad
         // u = dy B: each of the r*slots columns sums over its own module's `out` rows only
         d.Mvalid = m->cur_M; d.n_algo = m->r; 
         d.C = u; d.ldc = ln.kext;
+        // u inside the dgrad GEMM itself (the ping-pong kernel computes it from the dy tiles it streams through LDS: gemm_pp.hip,
+        // ND > 0) when no producer of dy delivered it: deep products always, shallow ones at small batches, where a separate
+        // skinny launch is pure latency (17 - 22 us for 6 - 12 k rows)
+        bool fused = false;
+        if (!u_ready && !vl_drop_on(m) && ln.out >= down_min_k(m, Mpad) && ln.kext == 64 && epi == EPI_STORE_H16) {
+            GemmArgs f = g;
+            f.k2_algo = m->r * (int)ln.slots.size();
+            f.k2_used = ext_cols(m, ln);
+            add_ext(f, u, ln.kext, ln.Au, ln.kext, ln.kext);
+            f.down_W = ln.Bd; f.down_ldw = ln.out; f.down_out = u; f.down_ld = ln.kext;
+            f.down_groups = ext_cols(m, ln) <= 16 ? 1 : ext_cols(m, ln) <= 32 ? 2 : 0;
+            if (f.down_groups && gemm_pp_fuses_down(f, epi)) { f.A2 = nullptr; launch_gemm(f, epi, 128, s); return; }
+        }
+        (void)fused;
         if (!u_ready) launch_gemm(d, EPI_STORE_H16, 64, s);
         if (vl_drop_on(m)) {
             // the LoRA branch saw dropout(x): d(x) = dy W + mask * (u (sA)), then the caller's epilogue factor.
@@ -270,6 +290,7 @@ int vl_create(const vl_config* cfg, vl_model** out) {
     { const char* dr = getenv("VITLORA_DEAD_ROWS"); m->dead_rows = !(dr && dr[0] == '0'); }
     { const char* fp = getenv("VITLORA_FUSE_PGD"); m->fuse_pgd = !(fp && fp[0] == '0'); }
     { const char* fk = getenv("VITLORA_FUSE_DOWN_MIN_K"); if (fk) m->fuse_down_min_k = atoi(fk); }
+    { const char* sm = getenv("VITLORA_SMALL_M_ROWS"); if (sm) m->small_m_rows = atoi(sm); }
     { const char* ai = getenv("VITLORA_ATTN_IMG"); m->attn_img_mode = ai ? (ai[0] == '1' ? 1 : 0) : -1; }
     { hipDeviceProp_t prop; m->num_cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256; }
     const int D = m->D, MLP = m->MLP, r = m->r;
