@@ -236,7 +236,7 @@ bool vl_drop_on(const vl_model* m) { return m->cur_train && m->r && m->cfg.lora_
 extern "C" {
 
 #ifndef VL_BF16
-const char* vl_version(void) { return "vitlora-hip 0.2 (gfx950; fp16 operands or fp32)"; }
+const char* vl_version(void) { return "vitlora-hip 0.3 (gfx950; fp16 / bf16 operands or fp32)"; }
 #endif
 #ifndef VL_BF16
 const char* vl_last_error(void) { return g_err.c_str(); }

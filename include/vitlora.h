@@ -64,7 +64,8 @@ typedef struct vl_config {
     int32_t lora_merged;  /* 0: rank-r update fused into the GEMMs as extra K tiles;
                              1: W' = W + s*B*A folded at vl_lora_commit (merge_and_unload,
                                 eval_compose.py:110) */
-    int32_t precision;    /* VL_PREC_F16 (default): fp16 operands, fp32 accumulation / residual stream (MFMA rate);
+    int32_t precision;    /* VL_PREC_F16 (default): fp16 operands and 16-bit residual streams, fp32 accumulation (MFMA rate);
+                             VL_PREC_BF16: the same kernels on bf16 operands (fp32's range: no VL_ERR_NONFINITE; 8 mantissa bits);
                              VL_PREC_F32: every operand and activation fp32 (v_mfma_f32_16x16x4_f32), the
                              parity mode held to 1e-3 against the reference's fp32 CPU path */
     int32_t reserved[3];
@@ -100,9 +101,10 @@ int vl_lora_commit(vl_model* m, void* stream);
  * whose flat buffer it updates, and a caller that writes through a pointer it kept calls
  * vl_params_changed.  vl_forward / vl_pgd_attack commit by themselves when the handle is dirty.  The contract is
  * therefore: writes the library can see (its own entry points) are never stale; a write through a KEPT pointer is the
- * caller's to announce (vl_params_changed).  The Python facade announces it for every torch-side write by itself (it
- * compares the flat Parameter's version counter before each forward / attack), so the reference's unmodified
- * torch.optim.Adam, copy_ and broadcast are covered (peft re-reads its Parameters on every forward). */
+ * caller's to announce (vl_params_changed).  The Python facade announces in-place torch operations on the flat
+ * Parameter itself (it compares the Parameter's version counter before each forward / attack), so the reference's
+ * unmodified torch.optim.Adam and parameter.copy_ are covered; writes through parameter.data or through a tensor obtained
+ * from vl_param_tensor / vl_param_flat do not move that counter and are the caller's to announce (mark_dirty()). */
 int vl_params_changed(vl_model* m);
 
 /* merge_and_unload for one adapted module (eval_compose.py:102-114): W_out = W_in + (alpha/r) B A,
