@@ -8,6 +8,7 @@
 #include <cstring>
 #include <vector>
 #include "attention32.hip"
+using namespace VLNS;      // the 16-bit sources live in vl_f16 / vl_bf16 (csrc/common.h)
 Profiler* g_prof = nullptr;
 int main(int argc, char** argv) {
     const int B = 256, T = 197, H = 12, D = 768;

@@ -1,12 +1,13 @@
 // Diagnostic: per-tile timeline of the persistent 256x256 GEMM workgroups (s_memtime stamps).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DVITLORA_GEMM_STAMPS -I<csrc> tools/gemm_stamp.hip -o tools/gemm_stamp
-//   tools/gemm_stamp N K epi      (epi: 0 bf16 store, 2 GELU, 3 GELU_BWD, 7 none)
+//   tools/gemm_stamp N K epi      (epi: 0 h16 store, 2 GELU, 3 GELU_BWD, 7 none)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
 #include <vector>
 #include "gemm256.hip"
+using namespace VLNS;      // the 16-bit sources live in vl_f16 / vl_bf16 (csrc/common.h)
 Profiler* g_prof = nullptr;
 __global__ void fill(unsigned short* p, size_t n, unsigned seed) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -16,7 +17,7 @@ __global__ void fill(unsigned short* p, size_t n, unsigned seed) {
 }
 int main(int argc, char** argv) {
     const int M = 50432, N = argc > 1 ? atoi(argv[1]) : 3072, K = argc > 2 ? atoi(argv[2]) : 768, epi = argc > 3 ? atoi(argv[3]) : 0;
-    bf16 *A, *W, *C, *C2, *R; float* bias;
+    h16 *A, *W, *C, *C2, *R; float* bias;
     hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&W, (size_t)N * K * 2); hipMalloc(&C, (size_t)M * N * 4); hipMalloc(&C2, (size_t)M * N * 2);
     hipMalloc(&R, (size_t)M * N * 4); hipMalloc(&bias, N * 4);
     fill<<<1024, 256>>>((unsigned short*)A, (size_t)M * K, 1); fill<<<1024, 256>>>((unsigned short*)W, (size_t)N * K, 2);
