@@ -49,8 +49,8 @@ def snap():
         out.append((f"z{l}", eng.debug_tensor("z", l).clone()))
         out.append((f"xs{2 * l + 2}", eng.debug_tensor("xs", 2 * l + 2).clone()))
     # head and backward side (shared buffers: what the last kernels left, i.e. layer 0's backward)
-    for n in ("logits", "dlogits", "loss_img", "gscale", "inv_gscale", "xhat", "rstd_f", "dz", "dh", "dctx", "dqkv", "u", "dres0", "dres1",
-              "dres_h", "grad_img", "stage_adv"):
+    for n in ("logits", "dlogits", "loss_img", "gscale", "inv_gscale", "xhat", "rstd_f", "dz", "dh", "dctx", "dqkv", "u",
+              "dres_h", "grad_img", "stage_adv"):        # (dres0 / dres1 exist in the fp32 mode only since the 16-bit gradient stream)
         out.append((n, eng.debug_tensor(n, 0).clone()))
     return out
 
