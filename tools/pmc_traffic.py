@@ -20,7 +20,7 @@ def kernel_source_sha16():
                      "adapting-pretrained-vision-transformers-with-lora-against-attack-vectors_amd", "csrc")
     h = hashlib.sha256()
     for fn in sorted(os.listdir(d)):
-        if fn.endswith((".hip", ".h")):
+        if fn.endswith((".hip", ".h")) or fn == "build.sh":        # build.sh: per-file compiler flags are part of the kernels
             h.update(fn.encode())
             h.update(open(os.path.join(d, fn), "rb").read())
     return h.hexdigest()[:16]
