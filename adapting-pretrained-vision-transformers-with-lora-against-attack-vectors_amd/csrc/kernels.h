@@ -88,9 +88,10 @@ void k_gather_rows(const h16* src, float* dst, int B, int D, int64_t stride, hip
 void k_scatter_rows(const float* src, h16* dst, int B, int D, int64_t stride, hipStream_t s);   // dst[b * stride] = src[b] (saturating)
 
 // patch.hip: adversarial-patch overlay (warp-and-paste) and its gradient w.r.t. the patch
-void k_patch_overlay(const float* img, const float* patch, const float* mats, float* out, int B, int S, int ps, int circle,
-                     hipStream_t s);
-void k_patch_overlay_bwd(const float* g, const float* mats, float* dpatch, int B, int S, int ps, int circle, hipStream_t s);
+void k_patch_overlay(const float* img, const float* patch, const float* mats, const float* persp, float* out, int B, int S,
+                     int ps, int circle, hipStream_t s);
+void k_patch_overlay_bwd(const float* g, const float* mats, const float* persp, float* dpatch, int B, int S, int ps, int circle,
+                         hipStream_t s);
 void k_clamp(float* x, float lo, float hi, int64_t n, hipStream_t s);
 
 // lora_grad.hip

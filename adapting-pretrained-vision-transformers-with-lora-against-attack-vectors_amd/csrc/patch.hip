@@ -6,6 +6,10 @@
 //                 M' = affine(mask,         angle, translate, scale; nearest,  zero fill)
 //     out = clamp(image * (1 - M') + P' * M', 0, 1)
 //
+// With distortion_scale_max > 0 (patch_attack.py:95) ART warps both canvases with torchvision's `perspective` (bilinear,
+// zero fill) BEFORE the affine: the kernels then evaluate affine o perspective o resize tap by tap (4 x 4 x 4 taps for the
+// patch, 4 x 4 behind the mask's nearest tap) from 8 homography coefficients per image; no intermediate canvas in HBM.
+//
 // restated from ART 1.20.1 / torchvision's tensor affine (grid_sample, align_corners = False); neither package is
 // installable here, so the oracle (oracle/patch_oracle.py) is a torch restatement of the same formulas and these
 // kernels are held to it ("parity unpinned").  The host passes the INVERSE affine matrix per image (6 floats,
@@ -56,9 +60,48 @@ __device__ __forceinline__ Warp warp_of(const float* m, int x, int y, int S) {
     return {m[0] * xb + m[1] * yb + m[2] + 0.5f * S - 0.5f, m[3] * xb + m[4] * yb + m[5] + 0.5f * S - 0.5f};
 }
 
+// torchvision `_perspective_grid` + grid_sample(align_corners = False): source position in the canvas of pixel (x1, y1) of
+// the perspective-warped canvas, u = (a (x1 + .5) + b (y1 + .5) + c) / (g (x1 + .5) + h (y1 + .5) + 1) - .5 (v alike).
+// Returns up to four in-canvas bilinear taps; q == nullptr (no distortion): the pixel itself with weight 1, which keeps the
+// undistorted path bit-identical to the two-stage form.
+struct Taps4 { int u[4], v[4]; float w[4]; int n; };
+__device__ __forceinline__ Taps4 persp_taps(const float* q, int x1, int y1, int S) {
+    Taps4 t;
+    if (q == nullptr) {
+        t.n = 1; t.u[0] = x1; t.v[0] = y1; t.w[0] = 1.f;
+        return t;
+    }
+    const float xb = (float)x1 + 0.5f, yb = (float)y1 + 0.5f;
+    const float den = q[6] * xb + q[7] * yb + 1.f;
+    const float u = (q[0] * xb + q[1] * yb + q[2]) / den - 0.5f, v = (q[3] * xb + q[4] * yb + q[5]) / den - 0.5f;
+    const float fu = floorf(u), fv = floorf(v);
+    const int u0 = (int)fu, v0 = (int)fv;
+    const float au = u - fu, av = v - fv;
+    t.n = 0;
+#pragma unroll
+    for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+        for (int du = 0; du < 2; ++du) {
+            const int cu = u0 + du, cv = v0 + dv;
+            if (cu < 0 || cu >= S || cv < 0 || cv >= S) continue;
+            t.u[t.n] = cu; t.v[t.n] = cv; t.w[t.n] = (du ? au : 1.f - au) * (dv ? av : 1.f - av);
+            ++t.n;
+        }
+    return t;
+}
+
+// mask canvas after the perspective warp at integer position (i, j)
+__device__ __forceinline__ float mask1_at(const float* q, int j, int i, int ps, int S, int circle) {
+    if (q == nullptr) return mask_at(j, i, ps, S, circle);
+    const Taps4 t = persp_taps(q, i, j, S);
+    float m = 0.f;
+    for (int k = 0; k < t.n; ++k) m += t.w[k] * mask_at(t.v[k], t.u[k], ps, S, circle);
+    return m;
+}
+
 __global__ __launch_bounds__(256) void patch_overlay_kernel(const float* __restrict__ img, const float* __restrict__ patch,
-                                                            const float* __restrict__ mats, float* __restrict__ out, int B,
-                                                            int S, int ps, int circle) {
+                                                            const float* __restrict__ mats, const float* __restrict__ persp,
+                                                            float* __restrict__ out, int B, int S, int ps, int circle) {
     const int64_t total = (int64_t)B * S * S;
     const float ratio = (float)ps / (float)S;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -66,11 +109,12 @@ __global__ __launch_bounds__(256) void patch_overlay_kernel(const float* __restr
         const int y = (int)((t / S) % S);
         const int b = (int)(t / ((int64_t)S * S));
         const float* m = mats + b * 6;
+        const float* q = persp ? persp + b * 8 : nullptr;
         const Warp wp = warp_of(m, x, y, S);
         // mask: nearest neighbour (round half to even, as grid_sample's nearbyint), zero outside the canvas
         const int nu = (int)nearbyintf(wp.u), nv = (int)nearbyintf(wp.v);
         float mk = 0.f;
-        if (nu >= 0 && nu < S && nv >= 0 && nv < S) mk = mask_at(nv, nu, ps, S, circle);
+        if (nu >= 0 && nu < S && nv >= 0 && nv < S) mk = mask1_at(q, nv, nu, ps, S, circle);
         float pv[3] = {0.f, 0.f, 0.f};
         if (mk != 0.f) {
             // patch: bilinear over the resized canvas, each canvas pixel itself bilinear over the ps x ps patch
@@ -84,12 +128,16 @@ __global__ __launch_bounds__(256) void patch_overlay_kernel(const float* __restr
                     const int cu = u0 + du, cv = v0 + dv;
                     if (cu < 0 || cu >= S || cv < 0 || cv >= S) continue;
                     const float wa = (du ? au : 1.f - au) * (dv ? av : 1.f - av);
-                    const Tap ty = resize_tap(cv, ps, ratio), tx = resize_tap(cu, ps, ratio);
+                    const Taps4 pt = persp_taps(q, cu, cv, S);
+                    for (int k = 0; k < pt.n; ++k) {
+                        const float wk = wa * pt.w[k];
+                        const Tap ty = resize_tap(pt.v[k], ps, ratio), tx = resize_tap(pt.u[k], ps, ratio);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float* pc = patch + c * ps * ps;
-                        pv[c] += wa * (ty.w0 * (tx.w0 * pc[ty.i0 * ps + tx.i0] + tx.w1 * pc[ty.i0 * ps + tx.i1]) +
-                                       ty.w1 * (tx.w0 * pc[ty.i1 * ps + tx.i0] + tx.w1 * pc[ty.i1 * ps + tx.i1]));
+                        for (int c = 0; c < 3; ++c) {
+                            const float* pc = patch + c * ps * ps;
+                            pv[c] += wk * (ty.w0 * (tx.w0 * pc[ty.i0 * ps + tx.i0] + tx.w1 * pc[ty.i0 * ps + tx.i1]) +
+                                           ty.w1 * (tx.w0 * pc[ty.i1 * ps + tx.i0] + tx.w1 * pc[ty.i1 * ps + tx.i1]));
+                        }
                     }
                 }
         }
@@ -105,8 +153,8 @@ __global__ __launch_bounds__(256) void patch_overlay_kernel(const float* __restr
 // d(patch)[c][r][s] += sum over pixels g[b][c][y][x] * M' * (affine bilinear weight) * (resize bilinear weight).
 // One workgroup per (image, band of rows): sums in an LDS copy of the patch gradient, then one global atomic per entry.
 __global__ __launch_bounds__(256) void patch_overlay_bwd_kernel(const float* __restrict__ g, const float* __restrict__ mats,
-                                                                float* __restrict__ dpatch, int S, int ps, int circle,
-                                                                int bands) {
+                                                                const float* __restrict__ persp, float* __restrict__ dpatch,
+                                                                int S, int ps, int circle, int bands) {
     extern __shared__ float acc[];        // [3][ps][ps]
     const int n = 3 * ps * ps;
     for (int i = threadIdx.x; i < n; i += 256) acc[i] = 0.f;
@@ -115,13 +163,14 @@ __global__ __launch_bounds__(256) void patch_overlay_bwd_kernel(const float* __r
     const int rows = (S + bands - 1) / bands;
     const int y0 = band * rows, y1 = min(S, y0 + rows);
     const float* m = mats + b * 6;
+    const float* q = persp ? persp + b * 8 : nullptr;
     const float ratio = (float)ps / (float)S;
     for (int t = y0 * S + threadIdx.x; t < y1 * S; t += 256) {
         const int x = t % S, y = t / S;
         const Warp wp = warp_of(m, x, y, S);
         const int nu = (int)nearbyintf(wp.u), nv = (int)nearbyintf(wp.v);
         if (nu < 0 || nu >= S || nv < 0 || nv >= S) continue;
-        const float mk = mask_at(nv, nu, ps, S, circle);
+        const float mk = mask1_at(q, nv, nu, ps, S, circle);
         if (mk == 0.f) continue;
         float gv[3];
 #pragma unroll
@@ -136,15 +185,19 @@ __global__ __launch_bounds__(256) void patch_overlay_bwd_kernel(const float* __r
                 const int cu = u0 + du, cv = v0 + dv;
                 if (cu < 0 || cu >= S || cv < 0 || cv >= S) continue;
                 const float wa = (du ? au : 1.f - au) * (dv ? av : 1.f - av);
-                const Tap ty = resize_tap(cv, ps, ratio), tx = resize_tap(cu, ps, ratio);
+                const Taps4 pt = persp_taps(q, cu, cv, S);
+                for (int k = 0; k < pt.n; ++k) {
+                    const float wk = wa * pt.w[k];
+                    const Tap ty = resize_tap(pt.v[k], ps, ratio), tx = resize_tap(pt.u[k], ps, ratio);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    float* pc = acc + c * ps * ps;
-                    const float gw = gv[c] * wa;
-                    atomicAdd(pc + ty.i0 * ps + tx.i0, gw * ty.w0 * tx.w0);
-                    atomicAdd(pc + ty.i0 * ps + tx.i1, gw * ty.w0 * tx.w1);
-                    atomicAdd(pc + ty.i1 * ps + tx.i0, gw * ty.w1 * tx.w0);
-                    atomicAdd(pc + ty.i1 * ps + tx.i1, gw * ty.w1 * tx.w1);
+                    for (int c = 0; c < 3; ++c) {
+                        float* pc = acc + c * ps * ps;
+                        const float gw = gv[c] * wk;
+                        atomicAdd(pc + ty.i0 * ps + tx.i0, gw * ty.w0 * tx.w0);
+                        atomicAdd(pc + ty.i0 * ps + tx.i1, gw * ty.w0 * tx.w1);
+                        atomicAdd(pc + ty.i1 * ps + tx.i0, gw * ty.w1 * tx.w0);
+                        atomicAdd(pc + ty.i1 * ps + tx.i1, gw * ty.w1 * tx.w1);
+                    }
                 }
             }
     }
@@ -160,20 +213,21 @@ __global__ void clamp_kernel(float* __restrict__ x, float lo, float hi, int64_t 
 
 }  // namespace
 
-void k_patch_overlay(const float* img, const float* patch, const float* mats, float* out, int B, int S, int ps, int circle,
-                     hipStream_t s) {
+void k_patch_overlay(const float* img, const float* patch, const float* mats, const float* persp, float* out, int B, int S,
+                     int ps, int circle, hipStream_t s) {
     ProfScope prof_("patch_overlay_kernel", 0.0, (double)B * 3 * S * S * 8.0, s);
     const int64_t total = (int64_t)B * S * S;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(patch_overlay_kernel, dim3((unsigned)blocks), dim3(256), 0, s, img, patch, mats, out, B, S, ps, circle);
+    hipLaunchKernelGGL(patch_overlay_kernel, dim3((unsigned)blocks), dim3(256), 0, s, img, patch, mats, persp, out, B, S, ps, circle);
 }
-void k_patch_overlay_bwd(const float* g, const float* mats, float* dpatch, int B, int S, int ps, int circle, hipStream_t s) {
+void k_patch_overlay_bwd(const float* g, const float* mats, const float* persp, float* dpatch, int B, int S, int ps, int circle,
+                         hipStream_t s) {
     ProfScope prof_("patch_overlay_bwd_kernel", 0.0, (double)B * 3 * S * S * 4.0, s);
     (void)hipMemsetAsync(dpatch, 0, (size_t)3 * ps * ps * sizeof(float), s);
     const int bands = 8;
     hipLaunchKernelGGL(patch_overlay_bwd_kernel, dim3(B * bands), dim3(256), (size_t)3 * ps * ps * sizeof(float), s, g, mats,
-                       dpatch, S, ps, circle, bands);
+                       persp, dpatch, S, ps, circle, bands);
 }
 void k_clamp(float* x, float lo, float hi, int64_t n, hipStream_t s) {
     int64_t blocks = (n + 255) / 256;

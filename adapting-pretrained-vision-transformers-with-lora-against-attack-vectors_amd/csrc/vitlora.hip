@@ -1114,28 +1114,35 @@ int vl_quantize_u8(const float* images, uint8_t* out_hwc, int batch, int channel
 
 // ---- adversarial patch (patch_attack.py: ART AdversarialPatchPyTorch) ------------------------------------
 #ifndef VL_BF16
-int vl_patch_apply(const float* images, const float* patch, const float* inv_affine, int batch, int image_size, int patch_size,
-                   int patch_type, float* out, void* stream) {
-    if (!images || !patch || !inv_affine || !out || out == images) return fail(VL_ERR_ARG, "bad argument");
+static int patch_args_ok(int batch, int image_size, int patch_size, int patch_type) {
     if (batch <= 0 || image_size <= 0 || patch_size <= 0 || patch_size > 64 || patch_size > image_size)
         return fail(VL_ERR_UNSUPPORTED, "patch_size must be in [1, min(64, image_size)]");
     if (patch_type != 0 && patch_type != 1) return fail(VL_ERR_ARG, "patch_type: 0 = square, 1 = circle");
-    k_patch_overlay(images, patch, inv_affine, out, batch, image_size, patch_size, patch_type, (hipStream_t)stream);
+    return VL_OK;
+}
+int vl_patch_apply_persp(const float* images, const float* patch, const float* inv_affine, const float* persp, int batch,
+                         int image_size, int patch_size, int patch_type, float* out, void* stream) {
+    if (!images || !patch || !inv_affine || !out || out == images) return fail(VL_ERR_ARG, "bad argument");
+    if (int rc = patch_args_ok(batch, image_size, patch_size, patch_type)) return rc;
+    k_patch_overlay(images, patch, inv_affine, persp, out, batch, image_size, patch_size, patch_type, (hipStream_t)stream);
     if (!capturing((hipStream_t)stream)) return check_launch("vl_patch_apply");
     return VL_OK;
 }
-#endif
-
-#ifndef VL_BF16
-int vl_patch_grad(const float* grad_out, const float* inv_affine, int batch, int image_size, int patch_size, int patch_type,
-                  float* patch_grad, void* stream) {
+int vl_patch_apply(const float* images, const float* patch, const float* inv_affine, int batch, int image_size, int patch_size,
+                   int patch_type, float* out, void* stream) {
+    return vl_patch_apply_persp(images, patch, inv_affine, nullptr, batch, image_size, patch_size, patch_type, out, stream);
+}
+int vl_patch_grad_persp(const float* grad_out, const float* inv_affine, const float* persp, int batch, int image_size,
+                        int patch_size, int patch_type, float* patch_grad, void* stream) {
     if (!grad_out || !inv_affine || !patch_grad) return fail(VL_ERR_ARG, "bad argument");
-    if (batch <= 0 || image_size <= 0 || patch_size <= 0 || patch_size > 64 || patch_size > image_size)
-        return fail(VL_ERR_UNSUPPORTED, "patch_size must be in [1, min(64, image_size)]");
-    if (patch_type != 0 && patch_type != 1) return fail(VL_ERR_ARG, "patch_type: 0 = square, 1 = circle");
-    k_patch_overlay_bwd(grad_out, inv_affine, patch_grad, batch, image_size, patch_size, patch_type, (hipStream_t)stream);
+    if (int rc = patch_args_ok(batch, image_size, patch_size, patch_type)) return rc;
+    k_patch_overlay_bwd(grad_out, inv_affine, persp, patch_grad, batch, image_size, patch_size, patch_type, (hipStream_t)stream);
     if (!capturing((hipStream_t)stream)) return check_launch("vl_patch_grad");
     return VL_OK;
+}
+int vl_patch_grad(const float* grad_out, const float* inv_affine, int batch, int image_size, int patch_size, int patch_type,
+                  float* patch_grad, void* stream) {
+    return vl_patch_grad_persp(grad_out, inv_affine, nullptr, batch, image_size, patch_size, patch_type, patch_grad, stream);
 }
 #endif
 

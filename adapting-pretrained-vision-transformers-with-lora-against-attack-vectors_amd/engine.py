@@ -308,23 +308,44 @@ class Engine:
 
     # -- adversarial patch (patch_attack.py) ---------------------------------------------------------
     def patch_apply(self, images: torch.Tensor, patch: torch.Tensor, inv_affine: torch.Tensor, patch_type: int,
-                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    out: Optional[torch.Tensor] = None, persp: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`persp` [B, 8]: torchvision perspective coefficients per image (distortion_scale_max > 0); None = no distortion."""
         images = self._check_images(images)
         patch = self._f32(patch)
         mats = self._f32(inv_affine)
         out = torch.empty_like(images) if out is None else out
-        check(self.lib.vl_patch_apply(C.c_void_p(images.data_ptr()), C.c_void_p(patch.data_ptr()), C.c_void_p(mats.data_ptr()),
-                                      images.shape[0], images.shape[2], patch.shape[-1], int(patch_type),
-                                      C.c_void_p(out.data_ptr()), self._stream()), "vl_patch_apply")
+        if persp is None:
+            check(self.lib.vl_patch_apply(C.c_void_p(images.data_ptr()), C.c_void_p(patch.data_ptr()), C.c_void_p(mats.data_ptr()),
+                                          images.shape[0], images.shape[2], patch.shape[-1], int(patch_type),
+                                          C.c_void_p(out.data_ptr()), self._stream()), "vl_patch_apply")
+        else:
+            q = self._persp(persp, images.shape[0])
+            check(self.lib.vl_patch_apply_persp(C.c_void_p(images.data_ptr()), C.c_void_p(patch.data_ptr()),
+                                                C.c_void_p(mats.data_ptr()), C.c_void_p(q.data_ptr()), images.shape[0],
+                                                images.shape[2], patch.shape[-1], int(patch_type), C.c_void_p(out.data_ptr()),
+                                                self._stream()), "vl_patch_apply_persp")
         return out
 
-    def patch_grad(self, grad_out: torch.Tensor, inv_affine: torch.Tensor, patch_size: int, patch_type: int) -> torch.Tensor:
+    def patch_grad(self, grad_out: torch.Tensor, inv_affine: torch.Tensor, patch_size: int, patch_type: int,
+                   persp: Optional[torch.Tensor] = None) -> torch.Tensor:
         g = self._f32(grad_out)
         mats = self._f32(inv_affine)
         dp = torch.empty(3, patch_size, patch_size, dtype=torch.float32, device=self.device)
-        check(self.lib.vl_patch_grad(C.c_void_p(g.data_ptr()), C.c_void_p(mats.data_ptr()), g.shape[0], g.shape[2],
-                                     int(patch_size), int(patch_type), C.c_void_p(dp.data_ptr()), self._stream()), "vl_patch_grad")
+        if persp is None:
+            check(self.lib.vl_patch_grad(C.c_void_p(g.data_ptr()), C.c_void_p(mats.data_ptr()), g.shape[0], g.shape[2],
+                                         int(patch_size), int(patch_type), C.c_void_p(dp.data_ptr()), self._stream()), "vl_patch_grad")
+        else:
+            q = self._persp(persp, g.shape[0])
+            check(self.lib.vl_patch_grad_persp(C.c_void_p(g.data_ptr()), C.c_void_p(mats.data_ptr()), C.c_void_p(q.data_ptr()),
+                                               g.shape[0], g.shape[2], int(patch_size), int(patch_type), C.c_void_p(dp.data_ptr()),
+                                               self._stream()), "vl_patch_grad_persp")
         return dp
+
+    def _persp(self, persp: torch.Tensor, batch: int) -> torch.Tensor:
+        q = self._f32(persp)
+        if tuple(q.shape) != (batch, 8):
+            raise ValueError(f"persp must be [{batch}, 8] (one set of perspective coefficients per image), got {tuple(q.shape)}")
+        return q
 
     def clamp_(self, x: torch.Tensor, lo: float, hi: float):
         check(self.lib.vl_clamp(C.c_void_p(x.data_ptr()), float(lo), float(hi), x.numel(), self._stream()), "vl_clamp")

@@ -2,8 +2,9 @@
 `AdversarialPatchPyTorch` that the reference uses (patch_attack.py:47-75 constructor arguments, :193-194 `generate`,
 :199-208 `apply_patch`), same argument names.
 
-Per optimiser step, all on the device: the host samples one (scale, rotation, shift) per image and builds the inverse
-affine matrices; `vl_patch_apply` warps and pastes the patch; `vl_forward` / `vl_loss_ce` / `vl_backward_input` give
+Per optimiser step, all on the device: the host samples one (scale, rotation, shift) per image -- and, with
+`distortion_scale_max > 0`, the four displaced corners of torchvision's `perspective` -- and builds the inverse affine
+matrices (and homography coefficients); `vl_patch_apply` warps and pastes the patch; `vl_forward` / `vl_loss_ce` / `vl_backward_input` give
 d(CE)/d(pixels); `vl_patch_grad` pulls it back onto the patch; with a process group the [3, ps, ps] gradient is summed
 over ranks (12 KB all-reduce); `vl_adam_step` + `vl_clamp` update the patch.
 
@@ -30,6 +31,30 @@ def inverse_affine_matrix(angle_deg: float, translate: Tuple[float, float], scal
     return m
 
 
+def perspective_endpoints(S: int, distortion_scale: float, gen: torch.Generator):
+    """ART `_random_overlay` (the corner draw of torchvision `RandomPerspective.get_params` at distortion_scale_max): the
+    corners [[0, 0], [S-1, 0], [S-1, S-1], [0, S-1]] of the S x S canvas move inwards by up to int(distortion * S // 2)
+    pixels per axis.  Returns [topleft, topright, botright, botleft] as integer [x, y] pairs."""
+    half = S // 2
+    d = int(distortion_scale * half)
+    r = lambda lo, hi: int(torch.randint(lo, hi, (1,), generator=gen).item())
+    return [[r(0, d + 1), r(0, d + 1)], [r(S - d - 1, S), r(0, d + 1)],
+            [r(S - d - 1, S), r(S - d - 1, S)], [r(0, d + 1), r(S - d - 1, S)]]
+
+
+def perspective_coeffs(S: int, endpoints):
+    """torchvision `_get_perspective_coeffs(startpoints = the canvas corners, endpoints)`: the eight coefficients (a..h) that
+    take a pixel of the WARPED canvas to its source, x_src = (a x + b y + c) / (g x + h y + 1), y_src = (d x + e y + f) / (...);
+    least squares in float64, returned as float32 values like torchvision does."""
+    start = [[0, 0], [S - 1, 0], [S - 1, S - 1], [0, S - 1]]
+    a = torch.zeros(8, 8, dtype=torch.float64)
+    for i, (p1, p2) in enumerate(zip(endpoints, start)):
+        a[2 * i] = torch.tensor([p1[0], p1[1], 1, 0, 0, 0, -p2[0] * p1[0], -p2[0] * p1[1]], dtype=torch.float64)
+        a[2 * i + 1] = torch.tensor([0, 0, 0, p1[0], p1[1], 1, -p2[1] * p1[0], -p2[1] * p1[1]], dtype=torch.float64)
+    b = torch.tensor(start, dtype=torch.float64).view(8)
+    return torch.linalg.lstsq(a, b, driver="gels").solution.to(torch.float32).tolist()
+
+
 class AdversarialPatchPyTorch:
     """Drop-in for the calls patch_attack.py makes.  `estimator` is a vitlora model (optionally wrapped in LogitsModel /
     NormalizedModel / PeftModel); images are [0, 1] NCHW, the model is fed (x - mean) / std inside the patch gather."""
@@ -41,9 +66,8 @@ class AdversarialPatchPyTorch:
                  seed: int = 0, mean=None, std=None, process_group=None):
         from .attacks import _unwrap
         from .engine import IMAGENET_MEAN, IMAGENET_STD
-        if distortion_scale_max != 0.0:
-            raise NotImplementedError("perspective distortion (distortion_scale_max > 0) is not on the accelerated path; "
-                                      "the reference runs with 0.0 (patch_attack.py:98)")
+        if not 0.0 <= distortion_scale_max < 1.0:
+            raise ValueError("distortion_scale_max must be in [0, 1)")            # ART's own check
         if patch_type not in ("circle", "square"):
             raise ValueError("patch_type must be 'circle' or 'square'")
         if optimizer not in ("Adam", "pgd"):
@@ -53,6 +77,7 @@ class AdversarialPatchPyTorch:
         self.vit = _unwrap(estimator)
         self.eng = self.vit._engine()
         self.rotation_max, self.scale_min, self.scale_max = float(rotation_max), float(scale_min), float(scale_max)
+        self.distortion_scale_max = float(distortion_scale_max)
         self.learning_rate, self.max_iter, self.batch_size = float(learning_rate), int(max_iter), int(batch_size)
         self.patch_shape, self.patch_location = tuple(patch_shape), patch_location
         self.patch_type, self.optimizer, self.targeted, self.verbose = patch_type, optimizer, bool(targeted), verbose
@@ -80,7 +105,8 @@ class AdversarialPatchPyTorch:
     # -- sampling (host) --------------------------------------------------------------------------------------
     def sample_params(self, n: int, scale: Optional[float] = None):
         """ART `_random_overlay`: scale ~ U(scale_min, scale_max) unless given; shifts ~ U(-pad, pad), pad = (S - scale*S)/2
-        (or fixed by patch_location); rotation ~ U(-rotation_max, rotation_max)."""
+        (or fixed by patch_location); rotation ~ U(-rotation_max, rotation_max); with distortion_scale_max > 0 a fifth entry:
+        the four displaced canvas corners of the perspective warp (`perspective_endpoints`)."""
         S = self.vit.arch.image_size
         ps = self.patch_shape[1]
         out = []
@@ -93,12 +119,24 @@ class AdversarialPatchPyTorch:
             else:
                 pad = int(math.floor(S - ps) / 2.0)
                 tx, ty = -pad + self.patch_location[0], -pad + self.patch_location[1]
-            out.append((sc, (2 * u[1] - 1) * self.rotation_max, tx, ty))
+            prm = (sc, (2 * u[1] - 1) * self.rotation_max, tx, ty)
+            if self.distortion_scale_max > 0.0:
+                prm += (perspective_endpoints(S, self.distortion_scale_max, self._gen),)
+            out.append(prm)
         return out
 
     def _matrices(self, params) -> torch.Tensor:
-        m = [inverse_affine_matrix(ang, (tx, ty), sc) for sc, ang, tx, ty in params]
+        m = [inverse_affine_matrix(p[1], (p[2], p[3]), p[0]) for p in params]
         return torch.tensor(m, dtype=torch.float32, device=self.eng.device)
+
+    def _persp(self, params) -> Optional[torch.Tensor]:
+        """[B, 8] homography coefficients when the parameter tuples carry corner displacements, else None (no distortion)."""
+        if not params or all(len(p) < 5 for p in params):
+            return None
+        S = self.vit.arch.image_size
+        ident = [[0, 0], [S - 1, 0], [S - 1, S - 1], [0, S - 1]]
+        q = [perspective_coeffs(S, p[4] if len(p) > 4 else ident) for p in params]
+        return torch.tensor(q, dtype=torch.float32, device=self.eng.device)
 
     # -- one optimiser step -----------------------------------------------------------------------------------
     def train_step(self, images: torch.Tensor, labels: torch.Tensor, params=None, global_count: int = 0) -> torch.Tensor:
@@ -113,13 +151,13 @@ class AdversarialPatchPyTorch:
             labels = labels.to(device=eng.device, dtype=torch.int64).contiguous()
             params = params if params is not None else self.sample_params(n_local)
             self.last_params = params
-            mats = self._matrices(params)
+            mats, persp = self._matrices(params), self._persp(params)
             eng.set_normalization(self.mean, self.std)
-            patched = eng.patch_apply(images, self._patch, mats, ptype)
+            patched = eng.patch_apply(images, self._patch, mats, ptype, persp=persp)
             eng.forward(patched, normalise=True, train=False)
             ce = eng.loss_ce(labels)
             gx, _ = eng.backward(True, False, tuple(images.shape))
-            g = eng.patch_grad(gx, mats, self.patch_shape[1], ptype)          # d CE / d patch (mean over the local images)
+            g = eng.patch_grad(gx, mats, self.patch_shape[1], ptype, persp=persp)   # d CE / d patch (mean over the local images)
         else:
             ce = torch.zeros((), device=eng.device)
             g = torch.zeros_like(self._patch)
@@ -179,7 +217,8 @@ class AdversarialPatchPyTorch:
         patch = self._patch if patch_external is None else torch.as_tensor(patch_external).to(self.eng.device).float()
         params = params if params is not None else self.sample_params(xt.shape[0], scale=scale)
         self.last_params = params
-        out = self.eng.patch_apply(xt, patch, self._matrices(params), 1 if self.patch_type == "circle" else 0)
+        out = self.eng.patch_apply(xt, patch, self._matrices(params), 1 if self.patch_type == "circle" else 0,
+                                   persp=self._persp(params))
         return out.cpu().numpy() if not isinstance(x, torch.Tensor) else out
 
 
@@ -196,4 +235,4 @@ class NormalizedModel(torch.nn.Module):
         return self.model((x - self.mean.to(x.device)) / self.std.to(x.device))
 
 
-__all__ = ["AdversarialPatchPyTorch", "NormalizedModel", "inverse_affine_matrix"]
+__all__ = ["AdversarialPatchPyTorch", "NormalizedModel", "inverse_affine_matrix", "perspective_endpoints", "perspective_coeffs"]

@@ -201,6 +201,16 @@ int vl_patch_apply(const float* images, const float* patch, const float* inv_aff
                    int patch_size, int patch_type, float* out, void* stream);
 int vl_patch_grad(const float* grad_out, const float* inv_affine, int batch, int image_size, int patch_size, int patch_type,
                   float* patch_grad, void* stream);
+/* The same overlay with ART's perspective distortion (patch_attack.py:95 --distortion_scale_max > 0): both canvases go through
+ * torchvision's perspective(startpoints, endpoints; bilinear, zero fill) BEFORE the affine.  persp [B,8] fp32 device = the
+ * per-image coefficients (a..h) of torchvision's _get_perspective_coeffs: canvas pixel (x, y) of the warped canvas reads the
+ * unwarped one at ((a X + b Y + c) / (g X + h Y + 1) - .5, (d X + e Y + f) / (g X + h Y + 1) - .5), X = x + .5, Y = y + .5
+ * (the host draws the corner displacements and solves for the coefficients: patch.py).  persp == NULL: no distortion,
+ * bit-identical to vl_patch_apply / vl_patch_grad. */
+int vl_patch_apply_persp(const float* images, const float* patch, const float* inv_affine, const float* persp, int batch,
+                         int image_size, int patch_size, int patch_type, float* out, void* stream);
+int vl_patch_grad_persp(const float* grad_out, const float* inv_affine, const float* persp, int batch, int image_size,
+                        int patch_size, int patch_type, float* patch_grad, void* stream);
 /* x <- clamp(x, lo, hi): the patch is clipped to the classifier's clip_values after every optimiser step. */
 int vl_clamp(float* x, float lo, float hi, int64_t n, void* stream);
 

@@ -9,6 +9,9 @@ torch and cites the call sites in the reference; no golden vector from the real 
   * overlay            ART `_random_overlay`: patch and mask resized (bilinear) to the image size, then per image
                        `affine(angle, translate, scale)` (patch: bilinear, mask: nearest, zero fill) and
                        `images * (1 - mask) + patch * mask`; `_predictions` clips the result to clip_values = (0, 1).
+  * perspective        distortion_scale_max > 0 (patch_attack.py:95): before the affine, mask and patch canvas both go through
+                       torchvision `perspective(startpoints = canvas corners, endpoints; bilinear, fill None)`:
+                       `_get_perspective_coeffs` (8 x 8 least squares) + `_perspective_grid` + grid_sample(zeros).
   * inverse matrix     torchvision `_get_inverse_affine_matrix` (centre = image centre, shear 0) + `_gen_affine_grid`
                        + `grid_sample(align_corners=False, padding_mode="zeros")`.
   * circular mask      ART `_get_circular_patch_mask`: 1 - clip((x^2 + y^2)^40, -1, 1) on linspace(-1, 1, ps)^2.
@@ -65,9 +68,38 @@ def affine(img: torch.Tensor, matrix, mode: str) -> torch.Tensor:
     return F.grid_sample(img, grid, mode=mode, padding_mode="zeros", align_corners=False)
 
 
+def perspective_coeffs(S: int, endpoints):
+    """torchvision `_get_perspective_coeffs`: rows (x', y', 1, 0, 0, 0, -x x', -x y') / (0, 0, 0, x', y', 1, -y x', -y y') per
+    corner pair ((x', y') = displaced corner, (x, y) = canvas corner), solved for the 8 coefficients in float64."""
+    import numpy as np
+    start = [(0, 0), (S - 1, 0), (S - 1, S - 1), (0, S - 1)]
+    rows, rhs = [], []
+    for (xe, ye), (xs, ys) in zip(endpoints, start):
+        rows.append([xe, ye, 1, 0, 0, 0, -xs * xe, -xs * ye])
+        rows.append([0, 0, 0, xe, ye, 1, -ys * xe, -ys * ye])
+        rhs += [xs, ys]
+    sol = np.linalg.lstsq(np.asarray(rows, dtype=np.float64), np.asarray(rhs, dtype=np.float64), rcond=None)[0]
+    return [float(np.float32(v)) for v in sol]
+
+
+def perspective(img: torch.Tensor, coeffs) -> torch.Tensor:
+    """torchvision tensor `perspective` (bilinear, fill None): `_perspective_grid` evaluates the homography at pixel centres
+    (x + .5, y + .5), normalises by half the canvas size and subtracts 1; grid_sample(align_corners=False, zeros)."""
+    n, _, h, w = img.shape
+    a, b, c, d, e, f, g, hh = coeffs
+    xs = torch.arange(w, dtype=torch.float32) + 0.5
+    ys = (torch.arange(h, dtype=torch.float32) + 0.5).unsqueeze(-1)
+    den = g * xs + hh * ys + 1.0
+    gx = (a * xs + b * ys + c) / (0.5 * w) / den - 1.0
+    gy = (d * xs + e * ys + f) / (0.5 * h) / den - 1.0
+    grid = torch.stack([gx, gy], dim=-1)[None].expand(n, h, w, 2)
+    return F.grid_sample(img, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+
+
 def overlay(images: torch.Tensor, patch: torch.Tensor, patch_type: str, params) -> torch.Tensor:
-    """images [B,3,S,S] in [0,1]; patch [3,ps,ps]; params: B tuples (scale, angle_deg, x_shift, y_shift).  Differentiable
-    in `patch`."""
+    """images [B,3,S,S] in [0,1]; patch [3,ps,ps]; params: B tuples (scale, angle_deg, x_shift, y_shift[, endpoints]) --
+    endpoints = the four displaced canvas corners of the perspective warp (distortion_scale_max > 0).  Differentiable in
+    `patch`."""
     B, _, S, _ = images.shape
     ps = patch.shape[-1]
     mask = base_mask(ps, patch_type).expand(3, ps, ps)[None]
@@ -75,10 +107,14 @@ def overlay(images: torch.Tensor, patch: torch.Tensor, patch_type: str, params) 
     patch_r = F.interpolate(patch[None], size=(S, S), mode="bilinear", align_corners=False)
     outs = []
     for i in range(B):
-        sc, ang, tx, ty = params[i]
+        sc, ang, tx, ty = params[i][:4]
         m = inverse_affine_matrix(ang, (tx, ty), sc)
-        mk = affine(mask_r, m, "nearest")
-        pp = affine(patch_r, m, "bilinear")
+        mk_i, pp_i = mask_r, patch_r
+        if len(params[i]) > 4:
+            q = perspective_coeffs(S, params[i][4])
+            mk_i, pp_i = perspective(mask_r, q), perspective(patch_r, q)
+        mk = affine(mk_i, m, "nearest")
+        pp = affine(pp_i, m, "bilinear")
         outs.append(images[i:i + 1] * (1 - mk) + pp * mk)
     return torch.clamp(torch.cat(outs), 0.0, 1.0)
 

@@ -92,6 +92,90 @@ def test_patch_train_steps_match_oracle(prec):
             assert set(torch.unique(got[:, inside]).tolist()) <= {0.0, 1.0}
 
 
+def _persp(P, S, params):
+    patch_mod = importlib.import_module(PKG + ".patch")
+    return torch.tensor([patch_mod.perspective_coeffs(S, p[4]) for p in params], dtype=torch.float32)
+
+
+@pytest.mark.parametrize("S,ps", [(64, 16), (224, 32)])
+@pytest.mark.parametrize("ptype", ["square", "circle"])
+def test_distorted_overlay_and_patch_gradient_match_oracle(S, ps, ptype):
+    """distortion_scale_max > 0 (patch_attack.py:95): perspective warp of both canvases before the affine.  The kernels
+    evaluate affine o perspective o resize tap by tap; the oracle runs torchvision's three resampling stages one after the
+    other (restated: PARITY UNPINNED)."""
+    P = pkg()
+    patch_mod = importlib.import_module(PKG + ".patch")
+    cfg, w, _, _, _ = make_case(batch=1, r=0)
+    eng = make_engine(cfg, w)
+    g = torch.Generator().manual_seed(7 * S + ps)
+    corners = [[0, 0], [S - 1, 0], [S - 1, S - 1], [0, S - 1]]
+    params = [PARAMS[0] + (corners,)]                                         # identity warp
+    for prm, dsc in zip(PARAMS[1:] + PARAMS[:2], (0.2, 0.5, 0.9, 0.3, 0.7, 0.45)):
+        params.append(prm + (patch_mod.perspective_endpoints(S, dsc, g),))
+    B = len(params)
+    img = torch.rand(B, 3, S, S, generator=g)
+    patch = torch.rand(3, ps, ps, generator=g)
+    mats, q = _mats(P, [p[:4] for p in params]), _persp(P, S, params)
+    ptype_i = 1 if ptype == "circle" else 0
+    eng._check_images = lambda t: eng._f32(t)
+    out = eng.patch_apply(img.cuda(), patch.cuda(), mats.cuda(), ptype_i, persp=q.cuda()).cpu()
+    ref = PO.overlay(img, patch, ptype, params)
+    diff = (out - ref).abs()
+    # the mask's nearest tap may flip at x.5 (as without distortion); a square mask is no longer 0 / 1 after the bilinear
+    # perspective stage, so a flipped tap shows as a small step rather than a whole pixel
+    assert (diff > 1e-4).float().mean().item() < 4e-4, (diff > 1e-4).float().mean().item()
+    assert diff.median().item() < 1e-6
+    # the identity warp reproduces the undistorted overlay (up to the coefficients' float rounding)
+    plain = eng.patch_apply(img[:1].cuda(), patch.cuda(), mats[:1].cuda(), ptype_i).cpu()
+    assert ((out[:1] - plain).abs() > 1e-4).float().mean().item() < 2e-4
+    # a distorted patch differs from the undistorted one
+    plain_all = eng.patch_apply(img.cuda(), patch.cuda(), mats.cuda(), ptype_i).cpu()
+    assert (plain_all[2] - out[2]).abs().max().item() > 0.05
+    gout = torch.randn(B, 3, S, S, generator=g)
+    p = patch.clone().requires_grad_(True)
+    (PO.overlay(img, p, ptype, params) * gout).sum().backward()
+    dp = eng.patch_grad(gout.cuda(), mats.cuda(), ps, ptype_i, persp=q.cuda()).cpu()
+    assert rel_l2(dp, p.grad) < 3e-3, rel_l2(dp, p.grad)
+    # (the gradient kernel sums with float atomics: two launches agree to rounding, not bit for bit)
+    assert rel_l2(eng.patch_grad(gout.cuda(), mats.cuda(), ps, ptype_i, persp=q.cuda()).cpu(), dp) < 1e-5
+    with pytest.raises(ValueError):
+        eng.patch_apply(img.cuda(), patch.cuda(), mats.cuda(), ptype_i, persp=q[:2].cuda())
+
+
+def test_patch_train_steps_with_distortion_match_oracle():
+    """ART `_train_step` x 3 with distortion_scale_max = 0.4 on a small ViT (fp32 mode): the sampled corner displacements ride
+    in the parameter tuples, CE and the patch after the steps against the oracle."""
+    P = pkg()
+    cfg, w, _, x, y = make_case(image_size=64, batch=6, r=0)
+    model = P.create_vit_model(cfg.num_labels, arch=P.ArchConfig(image_size=64, hidden=cfg.hidden, layers=cfg.layers, heads=cfg.heads,
+                                                                 mlp=cfg.mlp, num_labels=cfg.num_labels), precision="f32")
+    model.load_state_dict(w)
+    patch_mod = importlib.import_module(PKG + ".patch")
+    net = lambda z: O.vit_forward(w, cfg, O.normalise(z), None)
+    atk = patch_mod.AdversarialPatchPyTorch(P.LogitsModel(model), rotation_max=22.5, scale_min=0.4, scale_max=0.9, distortion_scale_max=0.4,
+                                            learning_rate=0.02, max_iter=3, batch_size=6, patch_shape=(3, 16, 16), patch_type="circle",
+                                            targeted=False, verbose=False, seed=13)
+    ref_patch = torch.full((3, 16, 16), 0.5, requires_grad=True)
+    opt = torch.optim.Adam([ref_patch], lr=0.02)
+    for _ in range(3):
+        params = atk.sample_params(6)
+        assert all(len(p) == 5 and len(p[4]) == 4 for p in params)
+        ce = atk.train_step(x, y, params=params)
+        opt.zero_grad()
+        loss = -torch.nn.functional.cross_entropy(net(PO.overlay(x, ref_patch, "circle", params)), y)
+        loss.backward()
+        opt.step()
+        with torch.no_grad():
+            ref_patch.clamp_(0, 1)
+        assert abs(float(ce) + loss.item()) < 2e-4 * abs(loss.item())
+    assert (atk._patch.cpu() - ref_patch.detach()).abs().max().item() < 2e-3
+    # without distortion the parameter tuples (and the random stream behind them) are what they were
+    a0 = patch_mod.AdversarialPatchPyTorch(P.LogitsModel(model), patch_shape=(3, 16, 16), verbose=False, seed=13)
+    assert all(len(p) == 4 for p in a0.sample_params(4))
+    with pytest.raises(ValueError):
+        patch_mod.AdversarialPatchPyTorch(P.LogitsModel(model), distortion_scale_max=1.0, patch_shape=(3, 16, 16))
+
+
 def test_vit_l16_full_depth_patch_gradient_small_batch():
     """BASELINE config 5's model at full depth: ViT-L/16 (24 layers, hidden 1024, 16 heads, mlp 4096) + LoRA r = 16, one EoT
     step on 2 images -- CE and d(CE)/d(patch) against the oracle (the patch gradient folds the whole 24-layer input
@@ -125,7 +209,7 @@ def test_patch_attack_cli_synthetic(tmp_path):
     import patch_attack
     patch_attack.main(["--model", "google_vit", "--source", "synthetic", "--output_dir", str(tmp_path), "--synthetic", "24",
                        "--arch", "tiny", "--batch_size", "8", "--patch_size", "16", "--max_iter", "3", "--splits", "test",
-                       "--patch_type", "circle", "square"])
+                       "--patch_type", "circle", "square", "--distortion_scale_max", "0.3"])
     for pt in ("circle", "square"):
         d = os.path.join(str(tmp_path), "google_vit", "synthetic", "test", f"patch_{pt}", "images")
         assert len(os.listdir(d)) == 24

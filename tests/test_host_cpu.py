@@ -252,3 +252,46 @@ def test_256_row_gemm_epilogues_on_the_path_build_without_vgpr_spills():
             m = re.search(r"gemm256_kernelILi(\d+)ELi(\d+)E", n)
             if m and int(m.group(2)) in (0, 2, 3, 4, 10):          # EPI_STORE_H16, GELU, GELU_BWD, PATCH_FWD, RESID_H16
                 assert v == 0, (tag, n, v)
+
+
+def test_perspective_warp_of_the_patch_overlay_host_and_oracle():
+    """distortion_scale_max > 0 (patch_attack.py:95): the corner draw, the homography coefficients the host hands to
+    vl_patch_apply_persp (patch.py) and the oracle's restatement of torchvision `perspective` (PARITY UNPINNED: torchvision is
+    not installable) -- known answers that follow from the definition alone."""
+    from oracle import patch_oracle as PO
+    patch_mod = importlib.import_module(PKG + ".patch")
+    S = 64
+    corners = [[0, 0], [S - 1, 0], [S - 1, S - 1], [0, S - 1]]
+    # identity: coefficients (1, 0, 0, 0, 1, 0, 0, 0); the warp returns the canvas
+    q = patch_mod.perspective_coeffs(S, corners)
+    assert max(abs(a - b) for a, b in zip(q, [1, 0, 0, 0, 1, 0, 0, 0])) < 1e-6
+    img = torch.rand(1, 3, S, S, generator=torch.Generator().manual_seed(1))
+    assert (PO.perspective(img, q) - img).abs().max().item() < 1e-4
+    # the corner draw: deterministic per generator, inside the bands ART draws from
+    g1, g2 = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+    for dist_scale in (0.2, 0.5, 0.9):
+        d = int(dist_scale * (S // 2))
+        for _ in range(20):
+            e = patch_mod.perspective_endpoints(S, dist_scale, g1)
+            assert e == patch_mod.perspective_endpoints(S, dist_scale, g2)
+            (tlx, tly), (trx, try_), (brx, bry), (blx, bly) = e
+            assert all(0 <= v <= d for v in (tlx, tly, try_, blx)) and all(S - d - 1 <= v <= S - 1 for v in (trx, brx, bry, bly))
+            # host coefficients == oracle coefficients (torch lstsq vs numpy lstsq), and each displaced corner reads its canvas corner
+            qh, qo = patch_mod.perspective_coeffs(S, e), PO.perspective_coeffs(S, e)
+            assert max(abs(a - b) for a, b in zip(qh, qo)) < 2e-5 * max(1.0, max(abs(v) for v in qo))
+            for (xe, ye), (xs, ys) in zip(e, corners):
+                den = qo[6] * xe + qo[7] * ye + 1
+                assert abs((qo[0] * xe + qo[1] * ye + qo[2]) / den - xs) < 2e-3 and abs((qo[3] * xe + qo[4] * ye + qo[5]) / den - ys) < 2e-3
+    # an axis-aligned shrink (corners move in by 8 pixels): the warp is a bilinear resize of the canvas into the inner square,
+    # zero outside it; at the inner square's own corners it reads the canvas corners
+    e = [[8, 8], [S - 9, 8], [S - 9, S - 9], [8, S - 9]]
+    w = PO.perspective(img, PO.perspective_coeffs(S, e))
+    assert w[..., :7, :].abs().max().item() == 0.0 and w[..., :, S - 7:].abs().max().item() == 0.0
+    # torchvision evaluates the homography at pixel CENTRES (x + .5) and shifts back by .5 afterwards: inside the inner square
+    # pixel x reads the canvas at (x + .5 - 8) * sc - .5, sc = (S - 1) / (S - 17) -- written here as a plain grid_sample
+    sc = (S - 1) / (S - 17)
+    pos = ((torch.arange(8, S - 8) + 0.5 - 8) * sc) / (0.5 * S) - 1.0
+    grid = torch.stack(torch.meshgrid(pos, pos, indexing="xy"), dim=-1)[None]
+    ref = torch.nn.functional.grid_sample(img, grid, mode="bilinear", padding_mode="zeros", align_corners=False)[0]
+    inner = w[0, :, 8:S - 8, 8:S - 8]
+    assert (inner - ref).abs().max().item() < 2e-4
