@@ -113,6 +113,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
     // per-lane byte offsets (kernel-invariant): row part (lr or the permuted W row) * ld + chunk
     const unsigned voA1 = ((unsigned)lr * (unsigned)p.lda1 + csw) * 2u, voA2 = ((unsigned)lr * (unsigned)p.lda2 + csw) * 2u;
     const unsigned voW1 = (wl * (unsigned)p.ldw1 + csw) * 2u, voW2 = (wl * (unsigned)p.ldw2 + csw) * 2u;
+    const float gather_rcp = p.patches > 0 ? 1.f / (float)p.patches : 0.f;
     auto issueA = [&](int bm, int h, int T) {
         constexpr int NA = BM / 128, BUF = (BM + BN) * BK;
         const bool ext = T >= nk1;
@@ -123,6 +124,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
         for (int i = 0; i < NA; ++i) {
             const int g = w * NA + i;
             const int r0 = (g / (BM / 32)) * (BM / 2) + h * (BM / 4) + (g % (BM / 32)) * 8;
+            if constexpr (EPI == EPI_PATCH_BWD || EPI == EPI_PATCH_PGD) {
+                if (p.a_gather && !ext) {
+                    // patch-embedding backward: GEMM row b*patches + pi reads token row b*tokens + 1 + pi of the gradient
+                    // stream (the CLS rows are skipped); rows past Mvalid read row 0.  m / patches through the reciprocal:
+                    // exact for m < 2^22 (the error of (m + .5) * rcp is far below the .5 / patches margin).
+                    const int mrow = bm * BM + r0 + lr;
+                    const int src = mrow < p.Mvalid ? mrow + (int)(((float)mrow + 0.5f) * gather_rcp) + 1 : 0;
+                    glds16(Ap + (size_t)(((unsigned)src * lda + k0 + csw) * 2u), dst + r0 * BK);
+                    continue;
+                }
+            }
             const unsigned so = ((unsigned)(bm * BM + r0) * lda + k0) * 2u;      // wave-uniform
             glds16(Ap + (size_t)(vo + so), dst + r0 * BK);
         }
@@ -401,6 +413,12 @@ void launch_one(const GemmArgs& a, int ntiles, int bm0, hipStream_t s) {
 
 template <int EPI>
 void launch_t(const GemmArgs& a, hipStream_t s) {
+    if constexpr (EPI == EPI_PATCH_BWD || EPI == EPI_PATCH_PGD) {
+        // the image-layout scatter (and the PGD step on top of it) does not fit the 256-row tile's register budget (26 spilled
+        // VGPRs, every reload a vmcnt(0) drain of the LDS-DMA queue): all rows as 128-row tiles, as many rounds as it takes
+        launch_one<128, EPI>(a, (a.M / 128) * (a.N / BN), 0, s);
+        return;
+    }
     int nbig = 0, nsmall = 0;
     plan_tiles(a.M, a.N, g_num_cus, &nbig, &nsmall);
     launch_one<256, EPI>(a, nbig, 0, s);
@@ -420,11 +438,12 @@ void set_attr() { set_attr1<256, EPI>(); set_attr1<128, EPI>(); }
 }  // namespace
 
 bool gemm256_supports(const GemmArgs& a, int epi) {
-    if (a.a_gather || epi == EPI_DROP_ACC) return false;   // row-gathered A / masked accumulate stay on the 128-row kernel
+    if (epi == EPI_DROP_ACC) return false;                 // masked accumulate stays on the 128-row kernel
+    if (a.a_gather && !(epi == EPI_PATCH_BWD || epi == EPI_PATCH_PGD)) return false;     // row-gathered A: the patch-gradient epilogues only
     if (a.N % BN || a.M % 128 || a.K1 % BK || a.K2 % BK) return false;
     if ((a.K1 + a.K2) / BK < 2) return false;
     int nb, ns;
-    (void)epi;
+    if (epi == EPI_PATCH_BWD || epi == EPI_PATCH_PGD) return true;
     return plan_tiles(a.M, a.N, g_num_cus ? g_num_cus : 256, &nb, &ns);
 }
 
@@ -439,7 +458,7 @@ int gemm256_init() {
         g_num_cus = prop.multiProcessorCount;
     if (g_num_cus <= 0) g_num_cus = 256;
     set_attr<EPI_STORE_H16>(); set_attr<EPI_RESID_F32>(); set_attr<EPI_GELU>(); set_attr<EPI_GELU_BWD>(); set_attr<EPI_RESID_H16>();
-    set_attr<EPI_PATCH_FWD>(); set_attr<EPI_PATCH_BWD>(); set_attr<EPI_STORE_F32>(); set_attr<EPI_NONE>();
+    set_attr<EPI_PATCH_FWD>(); set_attr<EPI_PATCH_BWD>(); set_attr<EPI_PATCH_PGD>(); set_attr<EPI_STORE_F32>(); set_attr<EPI_NONE>();
     return g_attr_err256;
 }
 
@@ -452,6 +471,7 @@ void launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
         case EPI_RESID_H16: launch_t<EPI_RESID_H16>(a, s); break;
         case EPI_PATCH_FWD: launch_t<EPI_PATCH_FWD>(a, s); break;
         case EPI_PATCH_BWD: launch_t<EPI_PATCH_BWD>(a, s); break;
+        case EPI_PATCH_PGD: launch_t<EPI_PATCH_PGD>(a, s); break;
         case EPI_STORE_F32: launch_t<EPI_STORE_F32>(a, s); break;
         case EPI_NONE: launch_t<EPI_NONE>(a, s); break;
     }

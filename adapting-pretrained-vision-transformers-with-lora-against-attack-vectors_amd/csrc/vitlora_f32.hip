@@ -3,6 +3,7 @@
 // writes it -- t = dropout(x) A^T, y += (alpha / r) t B^T (train_loras.py:79-95) -- from the fp32 master
 // parameters, unfused.  Reference arithmetic: HF modeling_vit.py:146-157 (embeddings), :164-189 (attention),
 // :241-254 (MLP), :257-286 (layer), :385, :560-561 (final LN + head).
+#include <algorithm>
 #include <cstring>
 
 #include "f32_kernels.h"
@@ -121,7 +122,10 @@ size_t f32_carve(vl_model* m, int B, int train, char* base, size_t off0) {
     w.f_dqkv = take((size_t)Mpad * 3 * D * 4);
     w.f_dz = take((size_t)Mpad * MLP * 4);
     w.f_u = take((size_t)Mpad * kext_max * 4);
-    w.f_tmp = take((size_t)Mpad * MLP * 4);
+    // f_tmp holds a masked LoRA product [M, in <= MLP] AND the patch-embedding backward's [B * NP, PK] product before its
+    // scatter: with an MLP narrower than PK = 3 P^2 (small test architectures) the second is the larger one (sized for the MLP
+    // alone until round 4, the patch gradient then ran past the end of the workspace)
+    w.f_tmp = take(std::max((size_t)Mpad * MLP, (size_t)Mppad * m->PK) * 4);
     w.f_xd = train ? take((size_t)Mpad * MLP * 4) : nullptr;
     return off;
 }

@@ -491,3 +491,35 @@ def test_ring_and_two_phase_attention_backward_agree(image_size, batch, monkeypa
                 assert rel_l2(outs[1][1], first[1]) < 1e-5                 # (LoRA gradients: fp32 atomics over token chunks, csrc/lora_grad.hip)
     finally:
         eng.set_option("attn_ring", 1)
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("image_size,batch,mlp", [(64, 4, 256), (224, 3, 256), (224, 3, 128), (64, 5, 1024)])
+def test_workspace_is_never_written_outside_its_planned_bytes(prec, image_size, batch, mlp):
+    """The workspace the caller hands over (vl_set_workspace) is the ONLY scratch memory the library may touch.  Guard bands of
+    1 MiB on both sides of the planned bytes keep their pattern through forward / loss / backward (input and parameter
+    gradients, eval and train plans), a PGD attack and an optimiser step -- for architectures whose MLP is narrower than the
+    flattened patch (3 P^2 = 768 columns): round 4 found the fp32 mode's patch-gradient product running past the end of a
+    buffer that was sized for the MLP alone (it corrupted whatever tensor the allocator had placed behind the workspace)."""
+    import ctypes as C
+    cfg, w, lora, x, y = make_case(image_size=image_size, batch=batch, mlp=mlp)
+    eng = make_engine(cfg, w, lora, precision=prec)
+    guard = 1 << 20
+    for train in (False, True):
+        n = eng.workspace_bytes(batch, train)
+        buf = torch.full((n + 2 * guard + 512,), 0xA5, dtype=torch.uint8, device="cuda")
+        base = (buf.data_ptr() + guard + 255) // 256 * 256
+        off = base - buf.data_ptr()
+        eng.plan(batch, train)
+        eng._ws = buf                                            # the engine keeps the tensor alive; the library gets the inner range
+        assert eng.lib.vl_set_workspace(eng.h, C.c_void_p(base), n) == 0
+        eng.forward(x.cuda(), normalise=True, train=train)
+        eng.loss_ce(y.cuda())
+        eng.backward(True, train, tuple(x.shape))
+        if not train:
+            eng.pgd_attack(x.cuda(), y.cuda(), 8 / 255, 2 / 255, 3, random_start=True, seed=1)
+        torch.cuda.synchronize()
+        assert bool((buf[:off] == 0xA5).all()), (prec, train, "bytes BEFORE the workspace were written")
+        tail = buf[off + n:]
+        bad = (tail != 0xA5).nonzero()
+        assert bad.numel() == 0, (prec, train, "bytes AFTER the workspace were written", int(bad[0]), int(bad[-1]), int(bad.numel()))

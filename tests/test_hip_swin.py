@@ -177,3 +177,34 @@ def test_swin_fp16_backward_out_of_range_is_flagged_as_nonfinite_not_as_a_bad_la
     g32 = e32.backward_input(tuple(x.shape))
     e32.check()
     assert torch.isfinite(g32).all()
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+def test_swin_workspace_is_never_written_outside_its_planned_bytes(prec):
+    """Same guard-band check as the ViT engine's (tests/test_hip_engine.py): 1 MiB of pattern on both sides of the bytes
+    vl_swin_plan asked for stays intact through forward / loss / input gradient / a PGD attack at an odd batch."""
+    import ctypes as C
+    depths = (1, 2, 2, 1)
+    m = hf_swin(12, seed=13, depths=depths)
+    ab = add_lora(m, 8, 16.0, seed=15)
+    eng = make_engine(m, 12, 8, ab, depths=depths, precision=prec)
+    g = torch.Generator().manual_seed(23)
+    x = torch.rand(3, 3, 224, 224, generator=g)
+    y = torch.randint(0, 12, (3,), generator=g)
+    n = C.c_size_t()
+    assert eng.lib.vl_swin_plan(eng.h, 3, C.byref(n)) == 0
+    n = n.value
+    guard = 1 << 20
+    buf = torch.full((n + 2 * guard + 512,), 0xA5, dtype=torch.uint8, device="cuda")
+    base = (buf.data_ptr() + guard + 255) // 256 * 256
+    off = base - buf.data_ptr()
+    eng._ws, eng._plan = buf, 3
+    assert eng.lib.vl_swin_set_workspace(eng.h, C.c_void_p(base), n) == 0
+    eng.forward(x.cuda(), normalise=True)
+    eng.loss_ce(y.cuda())
+    eng.backward_input(tuple(x.shape))
+    eng.pgd_attack(x.cuda(), y.cuda(), 8 / 255, 2 / 255, 2, random_start=True, seed=2)
+    torch.cuda.synchronize()
+    assert bool((buf[:off] == 0xA5).all()), (prec, "bytes BEFORE the workspace were written")
+    bad = (buf[off + n:] != 0xA5).nonzero()
+    assert bad.numel() == 0, (prec, "bytes AFTER the workspace were written", int(bad[0]), int(bad[-1]), int(bad.numel()))
