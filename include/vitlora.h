@@ -116,7 +116,9 @@ int vl_merge_weight(vl_model* m, int layer, uint32_t target, const float* W_in, 
 int vl_set_normalization(vl_model* m, const float mean[3], const float std[3]);
 
 /* Workspace: vl_plan returns the bytes needed for batches up to max_batch;
- * train != 0 additionally keeps what the LoRA weight-gradient needs. */
+ * train != 0 additionally keeps what the LoRA weight-gradient needs.  The bytes handed to vl_set_workspace are the ONLY
+ * scratch memory the library touches (guard-band tested) and belong to it until the next vl_set_workspace / vl_destroy;
+ * results do not depend on what they held before (tested with 0x00 against 0xFF fills). */
 int vl_plan(vl_model* m, int max_batch, int train, size_t* bytes);
 int vl_set_workspace(vl_model* m, void* ws, size_t bytes);
 
@@ -243,6 +245,8 @@ int vl_swin_param_flat(vl_swin* m, float** ptr, int64_t* numel);
 int vl_swin_param_tensor(vl_swin* m, int stage, int block, uint32_t target, int which, float** ptr, int64_t* numel);
 int vl_swin_set_normalization(vl_swin* m, const float mean[3], const float std[3]);
 int vl_swin_plan(vl_swin* m, int max_batch, size_t* bytes);
+/* as vl_set_workspace; additionally ZEROES the planned bytes (synchronously): the channel-padding columns of the 16-bit
+ * activations (96 -> 128 ...) are never written afterwards and meet zero weight columns.  The caller must not write there. */
 int vl_swin_set_workspace(vl_swin* m, void* ws, size_t bytes);
 int vl_swin_forward(vl_swin* m, const float* x, int batch, int normalise, float* logits_out, void* stream);
 int vl_swin_loss_ce(vl_swin* m, const int64_t* labels, float* loss_out, void* stream);

@@ -494,18 +494,26 @@ def test_ring_and_two_phase_attention_backward_agree(image_size, batch, monkeypa
 
 
 @pytest.mark.parametrize("prec", ["f16", "bf16", "f32"])
-@pytest.mark.parametrize("image_size,batch,mlp", [(64, 4, 256), (224, 3, 256), (224, 3, 128), (64, 5, 1024)])
-def test_workspace_is_never_written_outside_its_planned_bytes(prec, image_size, batch, mlp):
-    """The workspace the caller hands over (vl_set_workspace) is the ONLY scratch memory the library may touch.  Guard bands of
-    1 MiB on both sides of the planned bytes keep their pattern through forward / loss / backward (input and parameter
-    gradients, eval and train plans), a PGD attack and an optimiser step -- for architectures whose MLP is narrower than the
-    flattened patch (3 P^2 = 768 columns): round 4 found the fp32 mode's patch-gradient product running past the end of a
-    buffer that was sized for the MLP alone (it corrupted whatever tensor the allocator had placed behind the workspace)."""
+@pytest.mark.parametrize("image_size,batch,mlp,hidden,r,targets,merged,dropout", [
+    (64, 4, 256, 128, 8, ("q", "k", "v", "o", "fc2"), False, 0.0),
+    (224, 3, 256, 128, 8, ("q", "k", "v", "o", "fc2"), False, 0.0),
+    (224, 3, 128, 128, 4, ("q", "v"), False, 0.1),
+    (64, 5, 1024, 256, 16, ("q", "k", "v", "o", "fc1", "fc2"), False, 0.1),
+    (64, 2, 512, 128, 8, ("q", "k", "v", "o", "fc2"), True, 0.0),
+    (224, 1, 384, 384, 0, (), False, 0.0)])
+def test_workspace_is_never_written_outside_its_planned_bytes(prec, image_size, batch, mlp, hidden, r, targets, merged, dropout):
+    """The workspace the caller hands over (vl_set_workspace) is the ONLY scratch memory the library may touch, and nothing in it
+    is read before it is written.  (a) Guard bands of 1 MiB on both sides of the planned bytes keep their pattern through
+    forward / loss / backward (input and parameter gradients, eval and train plans) and a PGD attack -- for architectures
+    whose MLP is narrower than the flattened patch (3 P^2 = 768 columns): round 4 found the fp32 mode's patch-gradient product
+    running past the end of a buffer that was sized for the MLP alone (it corrupted whatever tensor the allocator had placed
+    behind the workspace).  (b) The same calls on a workspace pre-filled with 0x00 and with 0xFF bytes (NaN in every float
+    format) give bit-identical logits, loss, input gradient and attack result: an uninitialised read would show."""
     import ctypes as C
-    cfg, w, lora, x, y = make_case(image_size=image_size, batch=batch, mlp=mlp)
-    eng = make_engine(cfg, w, lora, precision=prec)
+    cfg, w, lora, x, y = make_case(image_size=image_size, batch=batch, mlp=mlp, hidden=hidden, heads=hidden // 64, r=r, targets=targets)
+    eng = make_engine(cfg, w, lora, merged=merged, dropout=dropout, precision=prec)
     guard = 1 << 20
-    for train in (False, True):
+    for train in ((False,) if (r == 0 or merged) else (False, True)):
         n = eng.workspace_bytes(batch, train)
         buf = torch.full((n + 2 * guard + 512,), 0xA5, dtype=torch.uint8, device="cuda")
         base = (buf.data_ptr() + guard + 255) // 256 * 256
@@ -513,13 +521,27 @@ def test_workspace_is_never_written_outside_its_planned_bytes(prec, image_size, 
         eng.plan(batch, train)
         eng._ws = buf                                            # the engine keeps the tensor alive; the library gets the inner range
         assert eng.lib.vl_set_workspace(eng.h, C.c_void_p(base), n) == 0
-        eng.forward(x.cuda(), normalise=True, train=train)
-        eng.loss_ce(y.cuda())
-        eng.backward(True, train, tuple(x.shape))
-        if not train:
-            eng.pgd_attack(x.cuda(), y.cuda(), 8 / 255, 2 / 255, 3, random_start=True, seed=1)
-        torch.cuda.synchronize()
-        assert bool((buf[:off] == 0xA5).all()), (prec, train, "bytes BEFORE the workspace were written")
-        tail = buf[off + n:]
-        bad = (tail != 0xA5).nonzero()
-        assert bad.numel() == 0, (prec, train, "bytes AFTER the workspace were written", int(bad[0]), int(bad[-1]), int(bad.numel()))
+        outs = []
+        for fill in (0x00, 0xFF):
+            buf[off:off + n] = fill
+            if dropout > 0:
+                eng.set_dropout_seed(7)
+            logits = eng.forward(x.cuda(), normalise=True, train=train).clone()
+            loss = eng.loss_ce(y.cuda()).clone()
+            gx, gp = eng.backward(True, train, tuple(x.shape))
+            res = [logits, loss, gx.clone()]
+            if gp is not None:
+                res.append(gp.clone())       # (LoRA gradients sum with float atomics: compared to rounding, not bit for bit)
+            if not train:
+                res.append(eng.pgd_attack(x.cuda(), y.cuda(), 8 / 255, 2 / 255, 3, random_start=True, seed=1).clone())
+            torch.cuda.synchronize()
+            outs.append(res)
+            assert bool((buf[:off] == 0xA5).all()), (prec, train, "bytes BEFORE the workspace were written")
+            bad = (buf[off + n:] != 0xA5).nonzero()
+            assert bad.numel() == 0, (prec, train, "bytes AFTER the workspace were written", int(bad[0]), int(bad[-1]), int(bad.numel()))
+        for k, (a, b) in enumerate(zip(*outs)):
+            assert not torch.isnan(b).any(), (prec, train, k, "NaN from a pre-filled workspace")
+            if train and k == 3:
+                assert rel_l2(a, b) < 1e-5, (prec, train, k)
+            else:
+                assert torch.equal(a, b), (prec, train, k, "result depends on what the workspace held before", (a != b).sum().item())
