@@ -1255,6 +1255,14 @@ static size_t swin_carve(vl_swin* m, int B, char* base) {
 
 int vl_swin_plan(vl_swin* m, int max_batch, size_t* bytes) {
     if (!m || !bytes || max_batch <= 0) return vl_fail(VL_ERR_ARG, "bad argument");
+    if (m->f16) {
+        // 32-bit byte offsets inside an operand (as the ViT path): stage 0's [B * 56 * 56, 4 C] h16 activation must stay below 4 GiB
+        const SStage& s0 = m->stages[0];
+        const int64_t rows = round_up((int64_t)max_batch * s0.H * s0.H, 512), wide = round_up(4 * (int64_t)s0.C, 128);
+        if (rows * wide >= ((int64_t)1 << 31))
+            return vl_fail(VL_ERR_UNSUPPORTED, "max_batch %d: an activation of %lld x %lld 16-bit elements exceeds the 4 GiB the kernels' "
+                           "32-bit operand offsets reach; split the batch", max_batch, (long long)rows, (long long)wide);
+    }
     *bytes = swin_carve(m, max_batch, nullptr);
     m->max_batch = -max_batch;          // planned, not armed
     return VL_OK;

@@ -2,6 +2,7 @@
 // plan and the launch sequences for forward, backward-to-input, LoRA backward and the PGD
 // loop (one hipGraph per iteration).  Host-side orchestration only: all arithmetic is in
 // gemm.hip / attention.hip / elementwise.hip / lora_grad.hip.
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -609,6 +610,16 @@ static void drop_graphs(vl_model* m) {
 
 int vl_plan(vl_model* m, int max_batch, int train, size_t* bytes) {
     if (!m || !bytes || max_batch <= 0) return fail(VL_ERR_ARG, "bad argument");
+    if (!m->f32) {
+        // the 16-bit GEMM / attention kernels address an operand with 32-bit byte offsets from its base: the widest activation
+        // ([token rows, max(3 D, MLP, 3 P^2)] h16) must stay below 4 GiB (ViT-B: 3 547 images per call, ViT-L: 2 660)
+        const int64_t rows = round_up((int64_t)max_batch * m->T, 256);
+        const int64_t wide = std::max<int64_t>(std::max<int64_t>(3 * m->D, m->MLP), m->PK);
+        if (rows * wide >= ((int64_t)1 << 31))
+            return fail(VL_ERR_UNSUPPORTED, "max_batch %d: an activation of %lld x %lld 16-bit elements exceeds the 4 GiB the kernels' 32-bit "
+                        "operand offsets reach; split the batch (at most %lld images per call for this architecture)", max_batch,
+                        (long long)rows, (long long)wide, (long long)((((int64_t)1 << 31) / wide - 255) / m->T));
+    }
     *bytes = carve(m, max_batch, train, nullptr);
     m->ws.max_batch = 0;   // a plan alone does not arm the workspace
     m->plan_batch = max_batch; m->plan_train = train;

@@ -545,3 +545,20 @@ def test_workspace_is_never_written_outside_its_planned_bytes(prec, image_size, 
                 assert rel_l2(a, b) < 1e-5, (prec, train, k)
             else:
                 assert torch.equal(a, b), (prec, train, k, "result depends on what the workspace held before", (a != b).sum().item())
+
+
+def test_plan_refuses_batches_beyond_the_32_bit_operand_offsets():
+    """The 16-bit kernels address an operand with 32-bit byte offsets from its base (LDS-DMA: wave-uniform base + per-lane
+    offset).  A batch whose widest activation would pass 4 GiB is refused at vl_plan, with the per-call limit in the message --
+    not executed with wrapped addresses.  ViT-B's MLP activation: [round_up(197 B, 256), 3072] h16 -> 3 547 images."""
+    lib_err = pkg_mod().VitLoraError
+    cfg, w, _, _, _ = make_case(image_size=224, hidden=768, heads=12, mlp=3072, layers=1, batch=1, r=0)
+    for prec in ("f16", "bf16"):
+        eng = make_engine(cfg, w, precision=prec)
+        assert eng.workspace_bytes(3547) > 0
+        with pytest.raises(lib_err, match="4 GiB"):
+            eng.workspace_bytes(3548)
+        with pytest.raises(lib_err, match="4 GiB"):
+            eng.plan(100000)
+    eng = make_engine(cfg, w, precision="f32")          # the fp32 parity kernels index with 64 bits
+    assert eng.workspace_bytes(3548) > 0

