@@ -13,141 +13,146 @@ namespace {
 
 constexpr int HD = 64;
 
-__device__ __forceinline__ void load_row64(const h16* p, float (&v)[HD]) {
+// sum over the 8 lanes that share a row (lane & 7 = 16-byte chunk of the 128-byte head row)
+__device__ __forceinline__ float row8_sum(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); return v + __shfl_xor(v, 4, 64);
+}
+// sum / max over the 8 row slots of a wave (lane >> 3), same chunk
+__device__ __forceinline__ float slot8_sum(float v) {
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64);
+}
+__device__ __forceinline__ float slot8_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 8, 64)); v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ void cvt8(const h16x8& t, float (&v)[8]) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const h16x8 t = *(const h16x8*)(p + 8 * c);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[8 * c + k] = h2f(t[k]);
-    }
+    for (int k = 0; k < 8; ++k) v[k] = h2f(t[k]);
 }
 
-// one wave per (image, head): scores of the CLS query against every key, softmax, context row.
+// One wave per (image, head): scores of the CLS query against every key, softmax, context row.  A wave walks the keys EIGHT ROWS
+// AT A TIME: lane = (row slot r = lane >> 3, chunk c = lane & 7), so a load instruction covers eight whole 128-byte head rows
+// (round 4; lane = key row made every lane walk its own row, 16 bytes of 64 different lines per instruction: 50 / 155 us per
+// launch forward / backward at batch 256 against the 28 / 70 us their bytes take).  Dot products are 8-element partial sums per
+// lane + a 3-step butterfly over the row's lanes.
 // ctx_c [B, D] h16 (compact), lse_c [B, H] fp32 (base-2 log-sum-exp of the scaled scores, as attention32.hip saves it)
 __global__ __launch_bounds__(256) void attn_cls_fwd_kernel(const h16* __restrict__ qkv, h16* __restrict__ ctx_c,
                                                            float* __restrict__ lse_c, int B, int T, int H, int D,
                                                            float scale_log2e) {
     __shared__ float sp[4][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane >> 3, c = lane & 7;
     const int idx = blockIdx.x * 4 + w;
     if (idx >= B * H) return;
     const int b = idx / H, hd = idx - b * H;
     const int ld = 3 * D;
     const h16* base = qkv + (size_t)b * T * ld;
-    float q[HD];
-    load_row64(base + hd * HD, q);
-    float s[4];
+    float q[8];
+    cvt8(*(const h16x8*)(base + hd * HD + 8 * c), q);
     float mx = -INFINITY;
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int j = lane + 64 * jj;
-        s[jj] = -INFINITY;
+    for (int j0 = 0; j0 < T; j0 += 8) {
+        const int j = j0 + r;
+        float a = 0.f;
         if (j < T) {
-            const h16* kr = base + (size_t)j * ld + D + hd * HD;
-            float a = 0.f;
+            float k[8];
+            cvt8(*(const h16x8*)(base + (size_t)j * ld + D + hd * HD + 8 * c), k);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const h16x8 kc = *(const h16x8*)(kr + 8 * c);
+            for (int e = 0; e < 8; ++e) a = fmaf(q[e], k[e], a);
+        }
+        a = row8_sum(a);
+        if (j < T) { mx = fmaxf(mx, a); if (c == 0) sp[w][j] = a; }
+    }
+    mx = slot8_max(mx);
+    const float mc = -mx * scale_log2e;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own LDS writes, read below by the same wave
+    float l = 0.f, acc[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a = fmaf(q[8 * c + e], h2f(kc[e]), a);
-            }
-            s[jj] = a;
-            mx = fmaxf(mx, a);
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int j0 = 0; j0 < T; j0 += 8) {
+        const int j = j0 + r;
+        if (j < T) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(sp[w][j], scale_log2e, mc));
+            l += p;
+            const float p16 = h2f(f2h(p));         // P enters the P V product as h16 (attention32.hip: pack8 of the score tile)
+            float v[8];
+            cvt8(*(const h16x8*)(base + (size_t)j * ld + 2 * D + hd * HD + 8 * c), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(p16, v[e], acc[e]);
         }
     }
-    mx = wave_max(mx);
-    const float mc = -mx * scale_log2e;
-    float l = 0.f;
+    l = slot8_sum(l);                              // every row once: the 8 slots hold disjoint rows, the chunk lanes the same ones
+    const float inv = 1.f / l;
+    h16x8 o;
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int j = lane + 64 * jj;
-        float p = 0.f;
-        if (j < T) p = __builtin_amdgcn_exp2f(fmaf(s[jj], scale_log2e, mc));
-        l += p;
-        sp[w][j] = h2f(f2h(p));            // P enters the P V product as h16 (attention32.hip: pack8 of the score tile)
-    }
-    l = wave_sum(l);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own LDS writes, read below by the same wave
-    float acc = 0.f;
-    const h16* vb = base + 2 * D + hd * HD + lane;
-#pragma unroll 8
-    for (int j = 0; j < T; ++j) acc = fmaf(sp[w][j], h2f(vb[(size_t)j * ld]), acc);
-    ctx_c[(size_t)b * D + hd * HD + lane] = f2h(acc * (1.f / l));
+    for (int e = 0; e < 8; ++e) o[e] = f2h(slot8_sum(acc[e]) * inv);
+    if (r == 0) *(h16x8*)(ctx_c + (size_t)b * D + hd * HD + 8 * c) = o;
     if (lane == 0) lse_c[idx] = mx * scale_log2e + log2f(l);
 }
 
 // backward of the same: dO = d(ctx row) (compact), O = ctx row (compact).  Writes the FULL dqkv [B*T, 3D]: dK, dV rows of every
-// token, dQ of the CLS row, zeros in the dQ part of all other rows.
+// token, dQ of the CLS row, zeros in the dQ part of all other rows.  Same eight-rows-per-instruction walk; ONE pass over K and V.
 __global__ __launch_bounds__(256) void attn_cls_bwd_kernel(const h16* __restrict__ qkv, const h16* __restrict__ ctx_c,
                                                            const h16* __restrict__ dctx_c, const float* __restrict__ lse_c,
                                                            h16* __restrict__ dqkv, int B, int T, int H, int D, float scale,
                                                            float scale_log2e) {
-    __shared__ float sds[4][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane >> 3, c = lane & 7;
     const int idx = blockIdx.x * 4 + w;
     if (idx >= B * H) return;
     const int b = idx / H, hd = idx - b * H;
     const int ld = 3 * D;
-    const h16* base = qkv + (size_t)b * T * ld;
-    h16* dbase = dqkv + (size_t)b * T * ld;
-    float q[HD], dO[HD];
-    load_row64(base + hd * HD, q);
-    load_row64(dctx_c + (size_t)b * D + hd * HD, dO);
+    const h16* base = qkv + (size_t)b * T * ld + hd * HD + 8 * c;
+    h16* dbase = dqkv + (size_t)b * T * ld + hd * HD + 8 * c;
+    float q[8], dO[8];
+    cvt8(*(const h16x8*)base, q);
+    cvt8(*(const h16x8*)(dctx_c + (size_t)b * D + hd * HD + 8 * c), dO);
     float delta = 0.f;
     {
-        float o[HD];
-        load_row64(ctx_c + (size_t)b * D + hd * HD, o);
+        float o[8];
+        cvt8(*(const h16x8*)(ctx_c + (size_t)b * D + hd * HD + 8 * c), o);
 #pragma unroll
-        for (int d = 0; d < HD; ++d) delta = fmaf(dO[d], o[d], delta);
+        for (int e = 0; e < 8; ++e) delta = fmaf(dO[e], o[e], delta);
+        delta = row8_sum(delta);
     }
     const float lse = lse_c[idx];
     h16x8 z8;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) z8[k] = (h16)0.f;
-#pragma unroll 1
-    for (int jj = 0; jj < 4; ++jj) {
-        const int j = lane + 64 * jj;
-        float ds16 = 0.f;
-        if (j < T) {
-            const h16* kr = base + (size_t)j * ld + D + hd * HD;
-            const h16* vr = base + (size_t)j * ld + 2 * D + hd * HD;
-            float s = 0.f, dp = 0.f;
+    for (int e = 0; e < 8; ++e) z8[e] = (h16)0.f;
+    float acc[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const h16x8 kc = *(const h16x8*)(kr + 8 * c), vc = *(const h16x8*)(vr + 8 * c);
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int j0 = 0; j0 < T; j0 += 8) {
+        const int j = j0 + r;
+        const bool live = j < T;
+        float k[8], v[8];
+        float sc = 0.f, dp = 0.f;
+        if (live) {
+            cvt8(*(const h16x8*)(base + (size_t)j * ld + D), k);
+            cvt8(*(const h16x8*)(base + (size_t)j * ld + 2 * D), v);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { s = fmaf(q[8 * c + e], h2f(kc[e]), s); dp = fmaf(dO[8 * c + e], h2f(vc[e]), dp); }
-            }
-            const float p = __builtin_amdgcn_exp2f(fmaf(s, scale_log2e, -lse));
-            const float p16 = h2f(f2h(p));
-            ds16 = h2f(f2h(p * (dp - delta)));       // dS enters its products as h16, the 1/sqrt(d) factor is applied to the sums
-            h16* rk = dbase + (size_t)j * ld + D + hd * HD;
-            h16* rv = dbase + (size_t)j * ld + 2 * D + hd * HD;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                h16x8 ok, ov;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    ok[e] = f2h(ds16 * q[8 * c + e] * scale);
-                    ov[e] = f2h(p16 * dO[8 * c + e]);
-                }
-                *(h16x8*)(rk + 8 * c) = ok;
-                *(h16x8*)(rv + 8 * c) = ov;
-            }
-            if (j > 0) {
-                h16* rq = dbase + (size_t)j * ld + hd * HD;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) *(h16x8*)(rq + 8 * c) = z8;
-            }
+            for (int e = 0; e < 8; ++e) { sc = fmaf(q[e], k[e], sc); dp = fmaf(dO[e], v[e], dp); }
         }
-        sds[w][j] = ds16;
+        sc = row8_sum(sc);
+        dp = row8_sum(dp);
+        if (live) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(sc, scale_log2e, -lse));
+            const float p16 = h2f(f2h(p));
+            const float ds16 = h2f(f2h(p * (dp - delta)));       // dS enters its products as h16, the 1/sqrt(d) factor is applied to the sums
+            h16x8 ok, ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ok[e] = f2h(ds16 * q[e] * scale);
+                ov[e] = f2h(p16 * dO[e]);
+                acc[e] = fmaf(ds16, k[e], acc[e]);
+            }
+            *(h16x8*)(dbase + (size_t)j * ld + D) = ok;
+            *(h16x8*)(dbase + (size_t)j * ld + 2 * D) = ov;
+            if (j > 0) *(h16x8*)(dbase + (size_t)j * ld) = z8;
+        }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    float acc = 0.f;
-    const h16* kb = base + D + hd * HD + lane;
-#pragma unroll 8
-    for (int j = 0; j < T; ++j) acc = fmaf(sds[w][j], h2f(kb[(size_t)j * ld]), acc);
-    dbase[hd * HD + lane] = f2h(acc * scale);
+    h16x8 dq;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dq[e] = f2h(slot8_sum(acc[e]) * scale);
+    if (r == 0) *(h16x8*)dbase = dq;
 }
 
 // dst[b][0..D) = src[b * stride .. + D)   (fp32, D % 4 == 0)
