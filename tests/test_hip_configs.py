@@ -373,3 +373,34 @@ def test_refused_inputs_fail_loudly():
     assert rel_l2(logits, O.vit_forward(w, cfg, O.normalise(x), None)) < TOL_ACT["f16"]
     with pytest.raises(P.VitLoraError):             # backward before any loss
         eng.backward(True, False, tuple(x.shape))
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_vitb_rank_32_on_the_reference_default_targets(prec):
+    """train_loras.py:441 trains ranks [8, 16, 32] by default; the golden LoRA vectors (made through the reference's own
+    modules) stop at 16, so r = 32 at ViT-B size is held to the oracle directly: logits, loss, input gradient and every d(A),
+    d(B), d(classifier) of a 2-image train-mode step (no dropout) -- 96 LoRA columns in the fused qkv projection."""
+    torch.set_num_threads(16)
+    cfg, w, x, y, _ = load_case("vitb")
+    x, y = x[:2], y[:2]
+    lora = O.init_lora(cfg, r=32, targets=TARGETS, seed=77, b_std=0.02)
+    eng = make_engine(cfg, w, lora, precision=prec)
+    sl = flat_slices(eng, cfg, lora)
+    xn = O.normalise(x)
+    logits = eng.forward(xn.cuda(), normalise=False, train=True).cpu()
+    loss = eng.loss_ce(y.cuda()).item()
+    gx, gp = eng.backward(True, True, tuple(x.shape))
+    gp = gp.cpu()
+    l_ref, lg_ref, grads = O.lora_train_grads(w, cfg, xn, y, lora)
+    assert rel_l2(logits, lg_ref) < TOL_ACT[prec] and abs(loss - l_ref.item()) < TOL_ACT[prec] * l_ref.item()
+    worst = 0.0
+    for key, g_ref in grads.items():
+        off, n, shape = sl[key]
+        e = rel_l2(gp[off:off + n].view(shape), g_ref)
+        worst = max(worst, e)
+        assert e < TOL_GRAD[prec], (key, e)
+    # input gradient w.r.t. the NORMALISED pixels the forward was given
+    xr = xn.clone().requires_grad_(True)
+    (g_in,) = torch.autograd.grad(torch.nn.functional.cross_entropy(O.vit_forward(w, cfg, xr, lora), y), xr)
+    assert rel_l2(gx.cpu(), g_in) < TOL_GRAD[prec], rel_l2(gx.cpu(), g_in)
+    print(f"r=32 ViT-B {prec}: worst LoRA-gradient error {worst:.2e}")

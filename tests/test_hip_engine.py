@@ -90,12 +90,15 @@ def test_loss_and_input_grad(image_size, batch, with_lora, prec):
     assert agree > 0.9995 and agree_all > (0.998 if prec == "f16" else 0.99995), (agree, agree_all)
 
 
-@pytest.mark.parametrize("r,targets", [(4, ("q", "v")), (8, ("q",)), (16, ("q", "v")), (16, ("o", "fc2")), (32, ("q", "o", "fc2")), (8, ("fc1", "fc2"))])
+@pytest.mark.parametrize("r,targets", [(4, ("q", "v")), (8, ("q",)), (16, ("q", "v")), (16, ("o", "fc2")), (32, ("q", "o", "fc2")), (8, ("fc1", "fc2")),
+                                       (32, ("q", "k", "v", "o", "fc2")), (32, ("q", "k", "v", "o", "fc1", "fc2"))])
 @pytest.mark.parametrize("prec", PRECS)
 def test_lora_down_fusion_variants(r, targets, prec):
     """The LoRA down-projections are computed by different kernels depending on r * modules (fused into the
     LayerNorm forward / backward rows for <= 8 / <= 16 columns, skinny GEMM otherwise): every route must agree
-    with the oracle on logits and on the input gradient."""
+    with the oracle on logits and on the input gradient.  r = 32 on the reference's default target set
+    (train_loras.py:441 --ranks default [8, 16, 32]; :81 target_modules) puts 96 LoRA columns into the fused qkv
+    projection: TWO extra K tiles."""
     cfg, w, lora, x, y = make_case(image_size=64, batch=4, r=r, targets=targets)
     eng = make_engine(cfg, w, lora, precision=prec)
     logits = eng.forward(x.cuda(), normalise=True)
@@ -281,9 +284,10 @@ def test_pgd_random_start_is_seeded_and_bounded():
     assert abs(u.mean().item()) < 0.02 and abs(u.std().item() - 3 ** -0.5) < 0.02
 
 
+@pytest.mark.parametrize("r", [8, 32])
 @pytest.mark.parametrize("prec", PRECS)
-def test_lora_train_grads(prec):
-    cfg, w, lora, x, y = make_case(batch=4, targets=("q", "k", "v", "o", "fc1", "fc2"))
+def test_lora_train_grads(prec, r):
+    cfg, w, lora, x, y = make_case(batch=4, r=r, targets=("q", "k", "v", "o", "fc1", "fc2"))
     eng = make_engine(cfg, w, lora, precision=prec)
     xn = O.normalise(x)
     logits = eng.forward(xn.cuda(), normalise=False, train=True)
@@ -500,6 +504,7 @@ def test_ring_and_two_phase_attention_backward_agree(image_size, batch, monkeypa
     (224, 3, 128, 128, 4, ("q", "v"), False, 0.1),
     (64, 5, 1024, 256, 16, ("q", "k", "v", "o", "fc1", "fc2"), False, 0.1),
     (64, 2, 512, 128, 8, ("q", "k", "v", "o", "fc2"), True, 0.0),
+    (64, 3, 512, 128, 32, ("q", "k", "v", "o", "fc2"), False, 0.1),
     (224, 1, 384, 384, 0, (), False, 0.0)])
 def test_workspace_is_never_written_outside_its_planned_bytes(prec, image_size, batch, mlp, hidden, r, targets, merged, dropout):
     """The workspace the caller hands over (vl_set_workspace) is the ONLY scratch memory the library may touch, and nothing in it
