@@ -505,7 +505,8 @@ def test_ring_and_two_phase_attention_backward_agree(image_size, batch, monkeypa
     (64, 5, 1024, 256, 16, ("q", "k", "v", "o", "fc1", "fc2"), False, 0.1),
     (64, 2, 512, 128, 8, ("q", "k", "v", "o", "fc2"), True, 0.0),
     (64, 3, 512, 128, 32, ("q", "k", "v", "o", "fc2"), False, 0.1),
-    (224, 1, 384, 384, 0, (), False, 0.0)])
+    (224, 1, 384, 384, 0, (), False, 0.0),
+    (224, 2, 4096, 1024, 16, ("q", "k", "v", "o", "fc2"), False, 0.0)])
 def test_workspace_is_never_written_outside_its_planned_bytes(prec, image_size, batch, mlp, hidden, r, targets, merged, dropout):
     """The workspace the caller hands over (vl_set_workspace) is the ONLY scratch memory the library may touch, and nothing in it
     is read before it is written.  (a) Guard bands of 1 MiB on both sides of the planned bytes keep their pattern through
@@ -567,3 +568,43 @@ def test_plan_refuses_batches_beyond_the_32_bit_operand_offsets():
             eng.plan(100000)
     eng = make_engine(cfg, w, precision="f32")          # the fp32 parity kernels index with 64 bits
     assert eng.workspace_bytes(3548) > 0
+
+
+@pytest.mark.parametrize("attn_img,opts", [("0", {}), ("1", {}), ("1", {"dead_rows": 0}), ("0", {"fuse_pgd": 0}), ("1", {"resid_epi": 0}),
+                                           ("0", {"resid_epi": 1, "attn_ring": 0})])
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+def test_workspace_guard_bands_hold_for_every_kernel_selection(prec, attn_img, opts, monkeypatch):
+    """The guard-band / pre-fill check of the test above on the kernel variants a small batch does not select by itself: the
+    per-image attention forms (chosen when the batch fills the chip; pinned here by VITLORA_ATTN_IMG), the two-phase attention
+    backward, every row of the last layer instead of the CLS rows only, the PGD step as its own kernel, the residual add in the
+    LayerNorm instead of the GEMM epilogue."""
+    import ctypes as C
+    monkeypatch.setenv("VITLORA_ATTN_IMG", attn_img)
+    cfg, w, lora, x, y = make_case(image_size=224, batch=3, mlp=256, hidden=128, heads=2, r=8)
+    eng = make_engine(cfg, w, lora, precision=prec)
+    try:
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        guard = 1 << 20
+        n = eng.workspace_bytes(3, False)
+        buf = torch.full((n + 2 * guard + 512,), 0xA5, dtype=torch.uint8, device="cuda")
+        base = (buf.data_ptr() + guard + 255) // 256 * 256
+        off = base - buf.data_ptr()
+        eng.plan(3, False)
+        eng._ws = buf
+        assert eng.lib.vl_set_workspace(eng.h, C.c_void_p(base), n) == 0
+        outs = []
+        for fill in (0x00, 0xFF):
+            buf[off:off + n] = fill
+            logits = eng.forward(x.cuda(), normalise=True).clone()
+            eng.loss_ce(y.cuda())
+            gx, _ = eng.backward(True, False, tuple(x.shape))
+            adv = eng.pgd_attack(x.cuda(), y.cuda(), 8 / 255, 2 / 255, 3, random_start=True, seed=1).clone()
+            torch.cuda.synchronize()
+            outs.append((logits, gx.clone(), adv))
+            assert bool((buf[:off] == 0xA5).all()) and bool((buf[off + n:] == 0xA5).all()), (prec, attn_img, opts)
+        for k, (a, b) in enumerate(zip(*outs)):
+            assert not torch.isnan(b).any() and torch.equal(a, b), (prec, attn_img, opts, k)
+    finally:
+        if "attn_ring" in opts:
+            eng.set_option("attn_ring", 1)           # process-wide switch: back to the default
