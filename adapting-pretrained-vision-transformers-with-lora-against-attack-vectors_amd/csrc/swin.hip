@@ -962,6 +962,7 @@ void swin16_block_fwd(vl_swin* m, SStage& st, SBlock& bk, const float* x_prev, b
     memset(&g, 0, sizeof g); g.C = bk.qkv16; g.ldc = st.L3;
     lin16_fwd(m, st, bk.qkv, st.h16b, st.LC, Mp, M, g, EPI_STORE_H16, s);
     const int64_t witems = (int64_t)B * nW * st.heads;
+    if (g_poison_lds) vl_poison_lds(s);      // test hook (prof.h): the window kernels keep K / V / Q / dO of a window in LDS
     hipLaunchKernelGGL(win16_fwd_kernel, dim3(win16_grid(witems, st.heads, 8)), dim3(64), 0, s,
                        bk.qkv16, st.L3, bk.table, st.ctx16, st.LC, bk.lse, B, Hs, Hs, Cs, st.heads, shift, witems);
     memset(&g, 0, sizeof g); g.C = st.delta16; g.ldc = st.LC;
@@ -988,6 +989,7 @@ void swin16_block_bwd(vl_swin* m, SStage& st, SBlock& bk, const float* gin, floa
     memset(&g, 0, sizeof g); g.C = st.dctx16; g.ldc = st.LC;
     lin16_dgrad(m, st, bk.o, st.gh16, st.LC, Mp, M, g, EPI_STORE_H16, s);
     const int64_t witems = (int64_t)B * nW * st.heads;
+    if (g_poison_lds) vl_poison_lds(s);      // test hook (prof.h): the window kernels keep K / V / Q / dO of a window in LDS
     hipLaunchKernelGGL(win16_bwd_kernel, dim3(win16_grid(witems, st.heads, 4)), dim3(64), 0, s,
                        bk.qkv16, st.L3, bk.table, st.dctx16, st.LC, bk.lse, st.dqkv16, B, Hs, Hs, Cs, st.heads, shift, witems);
     memset(&g, 0, sizeof g); g.C = st.dh16; g.ldc = st.LC;
@@ -1312,6 +1314,7 @@ static int swin_forward(vl_swin* m, const float* x, int B, int normalise, hipStr
             float* xout = bi + 1 < st.depth ? st.blocks[bi + 1].xa : (i < 3 ? m->dbig : m->xlast);
             k_ln_fwd_f32(bk.xa, m->h, bk.mean1, bk.rstd1, bk.ln1_g, bk.ln1_b, M, Cs, m->cfg.ln_eps, s);
             lin_fwd(m, bk.qkv, m->h, M, bk.qkvbuf, nullptr, s);
+            if (g_poison_lds) vl_poison_lds(s);      // test hook (prof.h): the window kernels keep K / V / Q / dO of a window in LDS
             hipLaunchKernelGGL(win_attn_fwd_kernel, dim3(nblk((int64_t)B * nW * st.heads, 4, 1 << 30)), dim3(256), 0, s, bk.qkvbuf,
                                bk.table, bk.ctx, bk.lse, B, Hs, Hs, Cs, st.heads, shift);
             lin_fwd(m, bk.o, bk.ctx, M, bk.xb, bk.xa, s);
@@ -1418,6 +1421,7 @@ static int swin_backward(vl_swin* m, float* grad_x, hipStream_t s) {
             lin_dgrad(m, bk.fc1, m->dbig, M, m->h, s);
             k_ln_bwd_f32(m->h, bk.xb, bk.mean2, bk.rstd2, bk.ln2_g, gcur, gnext, M, Cs, s);
             lin_dgrad(m, bk.o, gnext, M, m->a, s);                                       // d(ctx)
+            if (g_poison_lds) vl_poison_lds(s);      // test hook (prof.h): the window kernels keep K / V / Q / dO of a window in LDS
             hipLaunchKernelGGL(win_attn_bwd_kernel, dim3(nblk((int64_t)B * nW * st.heads, 2, 1 << 30)), dim3(128), 0, s, bk.qkvbuf,
                                bk.table, bk.ctx, m->a, bk.lse, m->dqkv, B, Hs, Hs, Cs, st.heads, shift);
             lin_dgrad(m, bk.qkv, m->dqkv, M, m->h, s);

@@ -17,8 +17,30 @@
 
 // This file is compiled twice (common.h): process-wide state and the entry points without a handle exist once, in the fp16 build.
 extern std::vector<vl_model*> g_vl_models;      // live handles of BOTH builds (vl_adam_step finds the model a flat buffer belongs to)
+extern long long g_poison_count;
 #ifndef VL_BF16
 Profiler* g_prof = nullptr;
+int g_poison_lds = 0;
+long long g_poison_count = 0;
+namespace {
+__global__ __launch_bounds__(256) void poison_lds_kernel(unsigned pattern, unsigned* sink) {
+    extern __shared__ unsigned lds_all[];
+    constexpr int N = 160 * 1024 / 4;
+    for (int i = threadIdx.x; i < N; i += 256) lds_all[i] = pattern;
+    __syncthreads();
+    if (sink && lds_all[(threadIdx.x * 97) % N] != pattern) *sink = 1;      // keeps the stores alive
+}
+}  // namespace
+void vl_poison_lds(hipStream_t s) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    // one workgroup owns a CU's whole LDS, so 2 x #CUs workgroups reach every CU of an otherwise idle stream
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(2 * cus), dim3(256), 160 * 1024, s, 0xFFFFFFFFu, (unsigned*)nullptr);
+    if (hipGetLastError() == hipSuccess) ++g_poison_count;
+}
 std::vector<vl_model*> g_vl_models;
 namespace {
 thread_local std::string g_err;
@@ -1064,7 +1086,7 @@ int vl_pgd_attack(vl_model* m, const float* x0, const int64_t* labels, int batch
     if (random_start) k_pgd_init(w.stage_adv, w.stage_x0, eps, 0.f, 1.f, seed, n, s);
     else HIPCHK(hipMemcpyAsync(w.stage_adv, w.stage_x0, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (steps > 0) {
-        if (!m->use_graph || g_prof) {
+        if (!m->use_graph || g_prof || g_poison_lds) {
             for (int i = 0; i < steps; ++i)
                 if ((rc = pgd_iteration(m, w.stage_x0, w.stage_labels, batch, eps, alpha, w.stage_adv, s))) return rc;
             if ((rc = check_launch("vl_pgd_attack"))) return rc;
@@ -1316,12 +1338,14 @@ int vl_debug_set_cus(vl_model* m, int cus) {
 //   "fuse_pgd"  1 (default): vl_pgd_attack applies the PGD step inside the patch-gradient GEMM epilogue; 0: gradient to HBM + K10
 //   "resid_epi" 1 (default): the residual add of the 16-bit stream sits in the o / fc2 GEMM epilogue; 0: in the LayerNorm after it
 //   "attn_ring" 1 (default): single-pass per-image attention backward; 0: the two-phase form (process-wide switch)
+//   "poison_lds" 0 (default); 1: every profiled launch is preceded by a kernel that fills every CU's LDS with NaN patterns (test hook)
 int vl_debug_set_option(vl_model* m, const char* name, int value) {
     if (!m || !name) return fail(VL_ERR_ARG, "null argument");
     if (!strcmp(name, "dead_rows")) m->dead_rows = value ? 1 : 0;
     else if (!strcmp(name, "fuse_pgd")) m->fuse_pgd = value ? 1 : 0;
     else if (!strcmp(name, "resid_epi")) m->resid_epi = value < 0 ? 0 : value > 2 ? 2 : value;
     else if (!strcmp(name, "attn_ring")) attention32_set_ring(value);        // process-wide
+    else if (!strcmp(name, "poison_lds")) g_poison_lds = value ? 1 : 0;      // process-wide test hook (prof.h); attacks then run eagerly
     else return fail(VL_ERR_ARG, "unknown option %s", name);
     drop_graphs(m);
     return VL_OK;
@@ -1384,6 +1408,7 @@ int vl_debug_counter(vl_model* m, const char* what, int64_t* value) {
     if (!strcmp(what, "graph_captures")) { *value = m->n_captures; return VL_OK; }
     if (!strcmp(what, "commits")) { *value = m->n_commits; return VL_OK; }
     if (!strcmp(what, "dirty")) { *value = m->dirty; return VL_OK; }
+    if (!strcmp(what, "lds_poisons")) { *value = g_poison_count; return VL_OK; }       // launches of the "poison_lds" test hook (process-wide)
     return fail(VL_ERR_ARG, "unknown counter %s", what);
 }
 

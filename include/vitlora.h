@@ -290,7 +290,9 @@ int vl_debug_set_option(vl_model* m, const char* name, int value);
 int vl_debug_set_cus(vl_model* m, int cus);   /* persistent GEMM grid size (diagnostic; default = the device's CU count) */
 
 /* Introspection for tests / profiling.  vl_debug_counter: "graph_captures" = PGD graphs captured so far,
- * "commits" = vl_lora_commit executions, "dirty" = 1 if parameters changed since the last commit. */
+ * "commits" = vl_lora_commit executions, "dirty" = 1 if parameters changed since the last commit, "lds_poisons" = launches of the
+ * "poison_lds" test hook (vl_debug_set_option: 1 = every profiled kernel launch is preceded by a kernel that fills every CU's
+ * LDS with NaN patterns; results must not change -- process-wide, attacks then run without the graph). */
 int vl_debug_counter(vl_model* m, const char* what, int64_t* value);
 int vl_debug_tensor(vl_model* m, const char* what, int layer, void** ptr, int64_t* numel, int* dtype);
 

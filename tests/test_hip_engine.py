@@ -608,3 +608,40 @@ def test_workspace_guard_bands_hold_for_every_kernel_selection(prec, attn_img, o
     finally:
         if "attn_ring" in opts:
             eng.set_option("attn_ring", 1)           # process-wide switch: back to the default
+
+
+@pytest.mark.parametrize("attn_img", ["0", "1"])
+@pytest.mark.parametrize("prec", ["f16", "bf16", "f32"])
+def test_results_do_not_depend_on_what_the_previous_kernel_left_in_lds(prec, attn_img, monkeypatch):
+    """LDS is not cleared between kernels: whatever the previous kernel on a CU left there is what an uninitialised read sees
+    (round 3: padded attention rows read as 0 x NaN after a GEMM had left fp16 pairs behind).  With the "poison_lds" hook every
+    launch is preceded by a kernel that fills all 160 KB of every CU's LDS with NaN patterns; logits, input gradient and a PGD
+    attack must come out bit for bit as without it, the LoRA gradients (float atomics) to rounding."""
+    monkeypatch.setenv("VITLORA_ATTN_IMG", attn_img)
+    for image_size, batch in ((224, 3), (64, 5)):
+        cfg, w, lora, x, y = make_case(image_size=image_size, batch=batch, r=8)
+        eng = make_engine(cfg, w, lora, precision=prec)
+        outs = []
+        n0 = eng.counter("lds_poisons")
+        try:
+            for poison in (0, 1):
+                eng.set_option("poison_lds", poison)
+                logits = eng.forward(x.cuda(), normalise=True).clone()
+                eng.loss_ce(y.cuda())
+                gx, _ = eng.backward(True, False, tuple(x.shape))
+                gx = gx.clone()
+                adv = eng.pgd_attack(x.cuda(), y.cuda(), 8 / 255, 2 / 255, 3, random_start=True, seed=5).clone()
+                eng.forward(x.cuda(), normalise=True, train=True)
+                eng.loss_ce(y.cuda())
+                _, gp = eng.backward(False, True)
+                torch.cuda.synchronize()
+                outs.append((logits, gx, adv, gp.clone()))
+        finally:
+            eng.set_option("poison_lds", 0)
+        assert eng.counter("lds_poisons") - n0 > 100, eng.counter("lds_poisons") - n0        # the hook really ran: one per profiled launch
+        for k, (a, b) in enumerate(zip(*outs)):
+            assert not torch.isnan(b).any(), (prec, attn_img, image_size, k)
+            if k == 3:
+                assert rel_l2(a, b) < 1e-5, (prec, attn_img, image_size, k)
+            else:
+                assert torch.equal(a, b), (prec, attn_img, image_size, k, int((a != b).sum()))

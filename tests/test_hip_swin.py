@@ -217,3 +217,36 @@ def test_swin_workspace_is_never_written_outside_its_planned_bytes(prec):
     for k, (a, b) in enumerate(zip(*outs)):
         assert not torch.isnan(b).any(), (prec, k)
         assert torch.equal(a, b), (prec, k, "second run differs from the first", (a != b).sum().item())
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+def test_swin_results_do_not_depend_on_what_the_previous_kernel_left_in_lds(prec):
+    """As tests/test_hip_engine.py::test_results_do_not_depend_on_what_the_previous_kernel_left_in_lds: with the process-wide
+    "poison_lds" hook (set through a ViT handle: include/vitlora.h) every GEMM / LayerNorm / window-attention launch of the Swin
+    path starts on LDS full of NaN patterns; logits, input gradient and a PGD attack come out bit for bit as without it."""
+    from helpers import make_case, make_engine as make_vit
+    cfgv, wv, _, _, _ = make_case(batch=1, r=0)
+    vit = make_vit(cfgv, wv)
+    depths = (1, 2, 2, 1)
+    m = hf_swin(12, seed=13, depths=depths)
+    ab = add_lora(m, 8, 16.0, seed=15)
+    eng = make_engine(m, 12, 8, ab, depths=depths, precision=prec)
+    g = torch.Generator().manual_seed(29)
+    x = torch.rand(3, 3, 224, 224, generator=g)
+    y = torch.randint(0, 12, (3,), generator=g)
+    outs = []
+    n0 = vit.counter("lds_poisons")
+    try:
+        for poison in (0, 1):
+            vit.set_option("poison_lds", poison)
+            logits = eng.forward(x.cuda(), normalise=True).clone()
+            eng.loss_ce(y.cuda())
+            gx = eng.backward_input(tuple(x.shape)).clone()
+            adv = eng.pgd_attack(x.cuda(), y.cuda(), 8 / 255, 2 / 255, 2, random_start=True, seed=2).clone()
+            torch.cuda.synchronize()
+            outs.append((logits, gx, adv))
+    finally:
+        vit.set_option("poison_lds", 0)
+    assert vit.counter("lds_poisons") - n0 > 50
+    for k, (a, b) in enumerate(zip(*outs)):
+        assert not torch.isnan(b).any() and torch.equal(a, b), (prec, k, int((a != b).sum()))
