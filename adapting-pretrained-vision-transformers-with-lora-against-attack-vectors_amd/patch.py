@@ -101,6 +101,8 @@ class AdversarialPatchPyTorch:
         self._m2 = torch.zeros_like(self._patch)
         self._t = 0
         self.last_params = None
+        self.skipped_steps = 0          # fp16 mode: optimiser steps dropped because a gradient left the fp16 range (telemetry)
+        self.steps_taken = 0
 
     # -- sampling (host) --------------------------------------------------------------------------------------
     def sample_params(self, n: int, scale: Optional[float] = None):
@@ -158,6 +160,14 @@ class AdversarialPatchPyTorch:
             ce = eng.loss_ce(labels)
             gx, _ = eng.backward(True, False, tuple(images.shape))
             g = eng.patch_grad(gx, mats, self.patch_shape[1], ptype, persp=persp)   # d CE / d patch (mean over the local images)
+            # fp16 mode: a backward that left the fp16 range is flagged, never silent.  The flag is consumed HERE, in the step it
+            # belongs to; the step is then dropped on EVERY rank -- a NaN gradient rides the one all-reduce below (as the LoRA
+            # train step does, train_loras.py) -- and the optimisation goes on with the next batch's transformations.
+            from ._lib import NonFiniteGradient
+            try:
+                eng.check()
+            except NonFiniteGradient:
+                g = torch.full_like(g, float("nan"))
         else:
             ce = torch.zeros((), device=eng.device)
             g = torch.zeros_like(self._patch)
@@ -169,6 +179,10 @@ class AdversarialPatchPyTorch:
             else:                                                         # equal shards assumed
                 dist.all_reduce(g, group=self.group)
                 g /= dist.get_world_size(self.group)
+        if bool(torch.isnan(g).any()):
+            self.skipped_steps += 1
+            return ce
+        self.steps_taken += 1
         # ART minimises loss = -CE (untargeted, Adam) or +CE (targeted); "pgd": patch += / -= lr * sign(grad)
         ascent = not self.targeted
         if self.optimizer == "pgd":

@@ -214,3 +214,31 @@ def test_patch_attack_cli_synthetic(tmp_path):
         d = os.path.join(str(tmp_path), "google_vit", "synthetic", "test", f"patch_{pt}", "images")
         assert len(os.listdir(d)) == 24
         assert os.path.exists(os.path.join(str(tmp_path), "google_vit", "synthetic", "test", f"patch_{pt}", "patch.npy"))
+
+
+def test_patch_step_that_leaves_the_fp16_range_is_dropped_and_counted():
+    """fp16 mode: an EoT step whose backward leaves the fp16 range (LayerNorm gains x 512 here) is never silent and never
+    applied -- the flag is consumed in the step it belongs to, the patch and Adam's moments stay as they were, the step is counted
+    (`skipped_steps`), and the optimisation carries on; bf16 on the same weights has no such event."""
+    P = pkg()
+    cfg, w, _, x, y = make_case(image_size=64, batch=6, r=0)
+    w2 = {k: (v * 512.0 if (k.endswith("layernorm_before.weight") or k.endswith("layernorm_after.weight")) else v) for k, v in w.items()}
+    patch_mod = importlib.import_module(PKG + ".patch")
+    arch = P.ArchConfig(image_size=64, hidden=cfg.hidden, layers=cfg.layers, heads=cfg.heads, mlp=cfg.mlp, num_labels=cfg.num_labels)
+    for prec, expect_skip in (("f16", True), ("bf16", False)):
+        model = P.create_vit_model(cfg.num_labels, arch=arch, precision=prec)
+        model.load_state_dict(w2)
+        atk = patch_mod.AdversarialPatchPyTorch(P.LogitsModel(model), learning_rate=0.05, max_iter=1, batch_size=6, patch_shape=(3, 16, 16),
+                                                scale_min=0.4, scale_max=0.9, targeted=False, verbose=False, seed=3)
+        before = atk._patch.clone()
+        ce = atk.train_step(x, y)
+        assert torch.isfinite(ce)
+        if expect_skip:
+            assert atk.skipped_steps == 1 and atk.steps_taken == 0 and atk._t == 0
+            assert torch.equal(atk._patch, before) and float(atk._m1.abs().max()) == 0.0
+            model._engine().check()                       # the flag was consumed by the step: nothing is left for a later call
+            model.load_state_dict(w)                      # unit gains through the same handle: the next step is taken
+            atk.train_step(x, y)
+            assert atk.steps_taken == 1 and not torch.equal(atk._patch, before)
+        else:
+            assert atk.skipped_steps == 0 and atk.steps_taken == 1 and not torch.equal(atk._patch, before)
