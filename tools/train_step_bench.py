@@ -36,4 +36,4 @@ P.check(eng.lib.vl_profile_begin()); step(9)
 buf = ctypes.create_string_buffer(1 << 16); P.check(eng.lib.vl_profile_report(buf, len(buf)))
 prof = json.loads(buf.value.decode())
 print(f"batch {B}, PGD-{K} inner: {dt*1e3:.2f} ms/step -> {B/dt:.1f} img/s")
-print({k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:10]})
+print({k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:24]})
