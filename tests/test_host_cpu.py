@@ -295,3 +295,15 @@ def test_perspective_warp_of_the_patch_overlay_host_and_oracle():
     ref = torch.nn.functional.grid_sample(img, grid, mode="bilinear", padding_mode="zeros", align_corners=False)[0]
     inner = w[0, :, 8:S - 8, 8:S - 8]
     assert (inner - ref).abs().max().item() < 2e-4
+
+
+def test_integration_md_indexes_every_abi_symbol():
+    """INTEGRATION.md section 3b lists EVERY entry point include/vitlora.h declares (with the reference callable it stands in for
+    and its caller here), and nothing the header does not declare."""
+    hdr = open(os.path.join(ROOT, "include", "vitlora.h")).read()
+    syms = set(re.findall(r"\b(vl_[a-z0-9_]+)\s*\(", hdr))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = doc[doc.index("### 3b."):doc.index("## 4. Multi-GPU")]
+    listed = set(re.findall(r"`(vl_[a-z0-9_]+)`", sec))
+    assert syms - listed == set(), sorted(syms - listed)
+    assert listed - syms == set(), sorted(listed - syms)
