@@ -79,6 +79,8 @@ struct Workspace {
 struct GraphEntry {
     int B; float eps, alpha;
     hipGraphExec_t exec;
+    int chains;
+    hipGraphExec_t exec1;     // chains == 2: the second half-batch's iteration (launched on the side stream)
 };
 
 struct vl_model {
@@ -105,6 +107,16 @@ struct vl_model {
     // PGD graph cache (one executable graph per (batch, eps, alpha); staging buffers make it pointer-independent)
     std::vector<GraphEntry> graphs;
     hipStream_t cap_stream = nullptr;
+    // vl_pgd_attack at small batches (round 4): the batch runs as TWO independent half-batch chains, captured as parallel branches
+    // of the one graph (fork / join by events on cap_stream / side_stream) -- a GEMM launch costs about one round more than its
+    // tiles (pipeline fill + exposed epilogue), and one chain's ends then meet the other's main loops.  Each chain has its own
+    // activation workspace (carved behind the main one for batches up to CHAIN_MAX_BATCH / 2).
+    static constexpr int CHAIN_MAX_BATCH = 128;
+    Workspace chain_ws[2];
+    int chain_batch = 0;          // images each chain workspace holds (0: none planned)
+    int pgd_chains = 0;           // "pgd_chains" / VITLORA_PGD_CHAINS: 0 = by batch size (2 for 2 <= batch <= 128), 1 = never, 2 = whenever it fits
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int64_t n_captures = 0, n_commits = 0;
     int use_graph = 1;
     int resid_epi = 2;    // residual add of the 16-bit stream in the GEMM epilogue (EPI_RESID_H16): 1 = attention output projection, 2 = + fc2, 0 = LayerNorm-side

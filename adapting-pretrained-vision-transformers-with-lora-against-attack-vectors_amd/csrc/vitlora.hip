@@ -312,6 +312,7 @@ int vl_create(const vl_config* cfg, vl_model** out) {
     { const char* re = getenv("VITLORA_RESID"); m->resid_epi = !re ? 2 : !strcmp(re, "ln") ? 0 : !strcmp(re, "o") ? 1 : 2; }
     { const char* dr = getenv("VITLORA_DEAD_ROWS"); m->dead_rows = !(dr && dr[0] == '0'); }
     { const char* fp = getenv("VITLORA_FUSE_PGD"); m->fuse_pgd = !(fp && fp[0] == '0'); }
+    if (const char* pc = getenv("VITLORA_PGD_CHAINS")) { const int v = atoi(pc); m->pgd_chains = v < 0 ? 0 : v > 2 ? 2 : v; }
     { const char* fk = getenv("VITLORA_FUSE_DOWN_MIN_K"); if (fk) m->fuse_down_min_k = atoi(fk); }
     { const char* sm = getenv("VITLORA_SMALL_M_ROWS"); if (sm) m->small_m_rows = atoi(sm); }
     { const char* ai = getenv("VITLORA_ATTN_IMG"); m->attn_img_mode = ai ? (ai[0] == '1' ? 1 : 0) : -1; }
@@ -381,8 +382,11 @@ int vl_create(const vl_config* cfg, vl_model** out) {
 
 int vl_destroy(vl_model* m) {
     if (!m) return VL_OK;
-    for (GraphEntry& g : m->graphs) (void)hipGraphExecDestroy(g.exec);
+    for (GraphEntry& g : m->graphs) { (void)hipGraphExecDestroy(g.exec); if (g.exec1) (void)hipGraphExecDestroy(g.exec1); }
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
+    if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->err_flag) (void)hipHostFree(m->err_flag);
     for (size_t i = 0; i < g_models.size(); ++i) if (g_models[i] == m) { g_models.erase(g_models.begin() + i); break; }
@@ -626,8 +630,24 @@ static size_t carve(vl_model* m, int B, int train, char* base) {
 }
 
 static void drop_graphs(vl_model* m) {
-    for (GraphEntry& g : m->graphs) (void)hipGraphExecDestroy(g.exec);
+    for (GraphEntry& g : m->graphs) { (void)hipGraphExecDestroy(g.exec); if (g.exec1) (void)hipGraphExecDestroy(g.exec1); }
     m->graphs.clear();
+}
+
+// Two-chain PGD (model.h): each chain's activations for up to `cb` images, carved behind the main workspace.  carve() fills
+// m->ws, so the chain structs are swapped in while it runs.
+static int chain_images(const vl_model* m, int max_batch) {
+    if (m->f32 || m->pgd_chains == 1 || max_batch < 2) return 0;
+    const int top = max_batch < vl_model::CHAIN_MAX_BATCH ? max_batch : vl_model::CHAIN_MAX_BATCH;
+    return (top + 1) / 2;
+}
+static size_t chain_bytes(vl_model* m, int max_batch) {
+    const int cb = chain_images(m, max_batch);
+    if (!cb) return 0;
+    std::swap(m->ws, m->chain_ws[0]);
+    const size_t one = carve(m, cb, 0, nullptr);
+    std::swap(m->ws, m->chain_ws[0]);
+    return 2 * one;
 }
 
 int vl_plan(vl_model* m, int max_batch, int train, size_t* bytes) {
@@ -642,7 +662,7 @@ int vl_plan(vl_model* m, int max_batch, int train, size_t* bytes) {
                         "operand offsets reach; split the batch (at most %lld images per call for this architecture)", max_batch,
                         (long long)rows, (long long)wide, (long long)((((int64_t)1 << 31) / wide - 255) / m->T));
     }
-    *bytes = carve(m, max_batch, train, nullptr);
+    *bytes = carve(m, max_batch, train, nullptr) + chain_bytes(m, max_batch);
     m->ws.max_batch = 0;   // a plan alone does not arm the workspace
     m->plan_batch = max_batch; m->plan_train = train;
     return VL_OK;
@@ -654,10 +674,19 @@ int vl_set_workspace(vl_model* m, void* wsp, size_t bytes) {
     if (m->plan_batch <= 0) return fail(VL_ERR_STATE, "vl_set_workspace before vl_plan");
     const int max_batch = m->plan_batch, train = m->plan_train;
     if (((uintptr_t)wsp) & 255) return fail(VL_ERR_ARG, "workspace must be 256-byte aligned");
-    const size_t need = carve(m, max_batch, train, nullptr);
+    const size_t main_need = carve(m, max_batch, train, nullptr);
+    const size_t need = main_need + chain_bytes(m, max_batch);
     if (bytes < need) return fail(VL_ERR_ARG, "workspace too small: %zu < %zu", bytes, need);
     carve(m, max_batch, train, (char*)wsp);
     m->ws.base = (char*)wsp; m->ws.bytes = bytes; m->ws.max_batch = max_batch; m->ws.train = train;
+    m->chain_batch = chain_images(m, max_batch);
+    for (int c = 0; c < 2 && m->chain_batch; ++c) {
+        char* cbase = (char*)wsp + main_need + (size_t)c * ((need - main_need) / 2);
+        std::swap(m->ws, m->chain_ws[c]);
+        carve(m, m->chain_batch, 0, cbase);
+        m->ws.base = cbase; m->ws.bytes = (need - main_need) / 2; m->ws.max_batch = m->chain_batch; m->ws.train = 0;
+        std::swap(m->ws, m->chain_ws[c]);
+    }
     if (hipMemset(wsp, 0, need) != hipSuccess) return fail(VL_ERR_HIP, "hipMemset(workspace) failed");
     drop_graphs(m);
     m->cur_B = 0;
@@ -1085,40 +1114,98 @@ int vl_pgd_attack(vl_model* m, const float* x0, const int64_t* labels, int batch
     HIPCHK(hipMemcpyAsync(w.stage_labels, labels, (size_t)batch * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     if (random_start) k_pgd_init(w.stage_adv, w.stage_x0, eps, 0.f, 1.f, seed, n, s);
     else HIPCHK(hipMemcpyAsync(w.stage_adv, w.stage_x0, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // two half-batch chains as parallel branches of the captured iteration (model.h): by batch size, or as "pgd_chains" says
+    float* const sx0 = w.stage_x0; float* const sadv = w.stage_adv; int64_t* const slab = w.stage_labels;    // the MAIN staging buffers
+    const int b0 = (batch + 1) / 2, b1 = batch - b0;
+    const bool chain_fits = m->chain_batch > 0 && batch >= 2 && b0 <= m->chain_batch;
+    const int chains = (chain_fits && (m->pgd_chains == 2 || (m->pgd_chains == 0 && batch <= vl_model::CHAIN_MAX_BATCH))) ? 2 : 1;
+    // one PGD iteration of the whole batch, enqueued on s0 (chains == 2: second half on s1 between a fork and a join event)
+    auto iteration = [&](hipStream_t s0, hipStream_t s1) -> int {
+        if (chains == 1) return pgd_iteration(m, sx0, slab, batch, eps, alpha, sadv, s0);
+        const int64_t off = (int64_t)b0 * 3 * m->S * m->S;
+        HIPCHK(hipEventRecord(m->ev_fork, s0));
+        HIPCHK(hipStreamWaitEvent(s1, m->ev_fork, 0));
+        int rc0, rc1;
+        std::swap(m->ws, m->chain_ws[0]);            // chain 0's activations become "the" workspace while its kernels are enqueued
+        rc0 = pgd_iteration(m, sx0, slab, b0, eps, alpha, sadv, s0);
+        std::swap(m->ws, m->chain_ws[0]);
+        std::swap(m->ws, m->chain_ws[1]);
+        rc1 = pgd_iteration(m, sx0 + off, slab + b0, b1, eps, alpha, sadv + off, s1);
+        std::swap(m->ws, m->chain_ws[1]);
+        HIPCHK(hipEventRecord(m->ev_join, s1));
+        HIPCHK(hipStreamWaitEvent(s0, m->ev_join, 0));
+        m->cur_B = 0;                 // the handle holds no forward of the whole batch: a backward call needs its own forward
+        return rc0 ? rc0 : rc1;
+    };
+    if (chains == 2) {
+        if (!m->side_stream) HIPCHK(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
+        if (!m->ev_fork) HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+        if (!m->ev_join) HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    }
     if (steps > 0) {
         if (!m->use_graph || g_prof || g_poison_lds) {
             for (int i = 0; i < steps; ++i)
-                if ((rc = pgd_iteration(m, w.stage_x0, w.stage_labels, batch, eps, alpha, w.stage_adv, s))) return rc;
+                if ((rc = iteration(s, m->side_stream))) return rc;
             if ((rc = check_launch("vl_pgd_attack"))) return rc;
         } else {
-            hipGraphExec_t exec = nullptr;
+            hipGraphExec_t exec = nullptr, exec1 = nullptr;
             for (GraphEntry& g : m->graphs)
-                if (g.B == batch && g.eps == eps && g.alpha == alpha) { exec = g.exec; break; }
+                if (g.B == batch && g.eps == eps && g.alpha == alpha && g.chains == chains) { exec = g.exec; exec1 = g.exec1; break; }
             if (!exec) {
                 // Captured cold: nothing has to run eagerly first.  (Round 2 ran the first iteration eagerly because replays of
                 // a graph captured in a fresh process differed from the eager result.  Cause, established in round 3 with
                 // tools/cold_capture_diag.py: the two hipMemsetAsync nodes of the backward did not take effect on replays when
                 // they were captured before the runtime's fill kernel had ever run; the first launch passed only because the
                 // workspace was still zero.  They are k_zero kernel nodes now: profiles/r03_cold_capture_*.txt.)
-                hipGraph_t graph = nullptr;
                 // capture on a private stream (the caller's may be the legacy default stream, which cannot
                 // capture); nothing executes during capture, the graph is launched on the caller's stream.
                 if (!m->cap_stream) HIPCHK(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
-                (void)hipGetLastError();
-                HIPCHK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
-                rc = pgd_iteration(m, w.stage_x0, w.stage_labels, batch, eps, alpha, w.stage_adv, m->cap_stream);
-                hipError_t e = hipStreamEndCapture(m->cap_stream, &graph);
-                if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-                if (e != hipSuccess) return fail(VL_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-                dump_graph(graph);
-                e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-                (void)hipGraphDestroy(graph);
-                if (e != hipSuccess) return fail(VL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
-                if (m->graphs.size() >= 8) { (void)hipGraphExecDestroy(m->graphs.front().exec); m->graphs.erase(m->graphs.begin()); }
-                m->graphs.push_back({batch, eps, alpha, exec});
+                // one captured iteration per chain: chains == 2 gives two graphs, each over its half of the staged batch and its
+                // own activation workspace, replayed on two streams that meet only at the start and the end of the attack
+                auto capture = [&](int c, hipGraphExec_t* out) -> int {
+                    hipGraph_t graph = nullptr;
+                    (void)hipGetLastError();
+                    HIPCHK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
+                    int rcc;
+                    if (chains == 1) rcc = pgd_iteration(m, sx0, slab, batch, eps, alpha, sadv, m->cap_stream);
+                    else {
+                        const int64_t off = c ? (int64_t)b0 * 3 * m->S * m->S : 0;
+                        std::swap(m->ws, m->chain_ws[c]);
+                        rcc = pgd_iteration(m, sx0 + off, slab + (c ? b0 : 0), c ? b1 : b0, eps, alpha, sadv + off, m->cap_stream);
+                        std::swap(m->ws, m->chain_ws[c]);
+                        m->cur_B = 0;         // the handle holds no forward of the whole batch
+                    }
+                    hipError_t e = hipStreamEndCapture(m->cap_stream, &graph);
+                    if (rcc) { if (graph) (void)hipGraphDestroy(graph); return rcc; }
+                    if (e != hipSuccess) return fail(VL_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+                    dump_graph(graph);
+                    e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+                    (void)hipGraphDestroy(graph);
+                    if (e != hipSuccess) return fail(VL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+                    return VL_OK;
+                };
+                if ((rc = capture(0, &exec))) return rc;
+                if (chains == 2 && (rc = capture(1, &exec1))) { (void)hipGraphExecDestroy(exec); return rc; }
+                if (m->graphs.size() >= 8) {
+                    (void)hipGraphExecDestroy(m->graphs.front().exec);
+                    if (m->graphs.front().exec1) (void)hipGraphExecDestroy(m->graphs.front().exec1);
+                    m->graphs.erase(m->graphs.begin());
+                }
+                m->graphs.push_back({batch, eps, alpha, exec, chains, exec1});
                 m->n_captures++;
             }
-            for (int i = 0; i < steps; ++i) HIPCHK(hipGraphLaunch(exec, s));
+            if (chains == 2) {
+                HIPCHK(hipEventRecord(m->ev_fork, s));
+                HIPCHK(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
+            }
+            for (int i = 0; i < steps; ++i) {
+                HIPCHK(hipGraphLaunch(exec, s));
+                if (chains == 2) HIPCHK(hipGraphLaunch(exec1, m->side_stream));
+            }
+            if (chains == 2) {
+                HIPCHK(hipEventRecord(m->ev_join, m->side_stream));
+                HIPCHK(hipStreamWaitEvent(s, m->ev_join, 0));
+            }
         }
     }
     HIPCHK(hipMemcpyAsync(adv_out, w.stage_adv, n * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1338,6 +1425,8 @@ int vl_debug_set_cus(vl_model* m, int cus) {
 //   "fuse_pgd"  1 (default): vl_pgd_attack applies the PGD step inside the patch-gradient GEMM epilogue; 0: gradient to HBM + K10
 //   "resid_epi" 1 (default): the residual add of the 16-bit stream sits in the o / fc2 GEMM epilogue; 0: in the LayerNorm after it
 //   "attn_ring" 1 (default): single-pass per-image attention backward; 0: the two-phase form (process-wide switch)
+//   "pgd_chains" 0 (default): vl_pgd_attack runs batches of 2 .. 128 images as two half-batch chains in parallel branches of the
+//               captured iteration; 1: one chain always; 2: two chains whenever the chain workspaces hold the halves
 //   "poison_lds" 0 (default); 1: every profiled launch is preceded by a kernel that fills every CU's LDS with NaN patterns (test hook)
 int vl_debug_set_option(vl_model* m, const char* name, int value) {
     if (!m || !name) return fail(VL_ERR_ARG, "null argument");
@@ -1346,6 +1435,7 @@ int vl_debug_set_option(vl_model* m, const char* name, int value) {
     else if (!strcmp(name, "resid_epi")) m->resid_epi = value < 0 ? 0 : value > 2 ? 2 : value;
     else if (!strcmp(name, "attn_ring")) attention32_set_ring(value);        // process-wide
     else if (!strcmp(name, "poison_lds")) g_poison_lds = value ? 1 : 0;      // process-wide test hook (prof.h); attacks then run eagerly
+    else if (!strcmp(name, "pgd_chains")) m->pgd_chains = value < 0 ? 0 : value > 2 ? 2 : value;    // 1: set BEFORE vl_plan to save the chain workspaces
     else return fail(VL_ERR_ARG, "unknown option %s", name);
     drop_graphs(m);
     return VL_OK;

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Small batches: does the PGD attack gain from running as TWO independent half-batch chains on two streams, so that the ends of
+one chain's kernels (pipeline fill, exposed epilogue: about one round per GEMM launch) meet the middles of the
+other's?  Arms per batch B, alternating in one process:  single = one handle, batch B;  dual = two handles, batch B/2 each, two
+streams, launched back to back.     python tools/dual_chain_small.py 64 32"""
+import importlib, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "adapting-pretrained-vision-transformers-with-lora-against-attack-vectors_amd"
+P = importlib.import_module(PKG); syn = importlib.import_module(PKG + ".synthetic")
+EPS, ALPHA, STEPS = 8 / 255, 2 / 255, 20
+T = ("q", "k", "v", "o", "fc2")
+arch = P.ArchConfig(num_labels=21)
+
+def make():
+    e = P.Engine(arch, P.LoraSpec(r=8, alpha=16.0, dropout=0.0, targets=T))
+    e.load_state_dict(syn.random_state_dict(arch, seed=0))
+    for (i, t), (A, Bm) in syn.random_lora(arch, 8, T, seed=1).items():
+        e.param(i, t, "A").copy_(A); e.param(i, t, "B").copy_(Bm)
+    e.commit()
+    return e
+
+NCH = int(os.environ.get("CHAINS", 2))
+single = make()
+chains = [make() for _ in range(NCH)]
+streams = [torch.cuda.Stream() for _ in range(NCH)]
+for B in [int(a) for a in sys.argv[1:]] or [64, 32]:
+    x, y = syn.random_batch(arch, B, seed=100); x, y = x.cuda(), y.cuda()
+    h = B // NCH
+    xs = [x[c * h:(c + 1) * h].contiguous() for c in range(NCH)]
+    ys = [y[c * h:(c + 1) * h].contiguous() for c in range(NCH)]
+    out = torch.empty_like(x)
+    outs = [torch.empty_like(v) for v in xs]
+    oa = outs[0]
+    def run_single():
+        single.pgd_attack(x, y, EPS, ALPHA, STEPS, seed=1, out=out)
+    def run_dual():
+        for c in range(NCH):
+            with torch.cuda.stream(streams[c]):
+                chains[c].pgd_attack(xs[c], ys[c], EPS, ALPHA, STEPS, seed=1, out=outs[c])
+    for f in (run_single, run_dual):
+        f(); torch.cuda.synchronize()
+    for rnd in range(3):
+        res = {}
+        for name, f in (("single", run_single), ("dual", run_dual)):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(3): f()
+            torch.cuda.synchronize(); res[name] = 3 * B / (time.perf_counter() - t0)
+        print(f"batch {B} round {rnd}: single {res['single']:.1f} img/s, dual ({NCH} x {h}) {res['dual']:.1f} img/s ({res['dual'] / res['single'] - 1:+.1%})", flush=True)
+    same = torch.equal(out[:h], oa)
+    print(f"batch {B}: first half of the single-chain result == chain 0 of the dual run: {same}")
