@@ -645,3 +645,54 @@ def test_results_do_not_depend_on_what_the_previous_kernel_left_in_lds(prec, att
                 assert rel_l2(a, b) < 1e-5, (prec, attn_img, image_size, k)
             else:
                 assert torch.equal(a, b), (prec, attn_img, image_size, k, int((a != b).sum()))
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+@pytest.mark.parametrize("image_size,batch", [(64, 2), (64, 5), (224, 3), (224, 32)])
+def test_two_chain_attack_equals_the_single_chain_attack(prec, image_size, batch):
+    """vl_pgd_attack runs batches of 2 .. 128 images as TWO half-batch chains (own activation workspaces, one captured iteration
+    each, two streams that meet at the start and the end of the attack: DESIGN.md section 3.7).  Images are independent, so the
+    result is the single-chain result bit for bit -- for odd batches (3 + 2), with and without the random start, graph replay and
+    eager, and whatever the option says; one capture event serves the whole attack."""
+    cfg, w, lora, x, y = make_case(image_size=image_size, batch=batch, r=8)
+    eng = make_engine(cfg, w, lora, precision=prec)
+    eps, alpha = 8 / 255, 2 / 255
+    outs = {}
+    for mode in (1, 0, 2):                          # 1: one chain; 0: by batch size (two here); 2: forced
+        eng.set_option("pgd_chains", mode)
+        c0 = eng.counter("graph_captures")
+        a = eng.pgd_attack(x.cuda(), y.cuda(), eps, alpha, 4, random_start=True, seed=9).clone()
+        b = eng.pgd_attack(x.cuda(), y.cuda(), eps, alpha, 4, random_start=False).clone()
+        assert eng.counter("graph_captures") - c0 == 1
+        eng.check()
+        outs[mode] = (a, b)
+        # the handle still serves the plain API afterwards (the chains leave no half-batch forward behind)
+        logits = eng.forward(x.cuda(), normalise=True)
+        eng.loss_ce(y.cuda())
+        gx, _ = eng.backward(True, False, tuple(x.shape))
+        outs[mode] += (logits.clone(), gx.clone())
+    for mode in (0, 2):
+        for k in range(4):
+            assert torch.equal(outs[mode][k], outs[1][k]), (prec, image_size, batch, mode, k, int((outs[mode][k] != outs[1][k]).sum()))
+    # eager (no graph) two-chain iterations: fork / join events around every iteration
+    eng.set_option("pgd_chains", 0)
+    eng.set_option("poison_lds", 1)
+    try:
+        e = eng.pgd_attack(x.cuda(), y.cuda(), eps, alpha, 4, random_start=True, seed=9)
+        assert torch.equal(e, outs[1][0])
+    finally:
+        eng.set_option("poison_lds", 0)
+
+
+def test_two_chain_attack_is_planned_away_when_switched_off_before_the_plan():
+    """ "pgd_chains" = 1 BEFORE vl_plan: no chain workspaces are carved (the planned bytes shrink) and attacks run as one chain."""
+    cfg, w, lora, x, y = make_case(image_size=64, batch=6, r=8)
+    eng = make_engine(cfg, w, lora)
+    with_chains = eng.workspace_bytes(6)
+    ref = eng.pgd_attack(x.cuda(), y.cuda(), 8 / 255, 2 / 255, 3, random_start=True, seed=2).clone()
+    eng2 = make_engine(cfg, w, lora)
+    eng2.set_option("pgd_chains", 1)
+    assert eng2.workspace_bytes(6) < with_chains
+    assert torch.equal(eng2.pgd_attack(x.cuda(), y.cuda(), 8 / 255, 2 / 255, 3, random_start=True, seed=2), ref)
+    eng2.set_option("pgd_chains", 2)               # asked for after the plan: there is no chain workspace, it stays one chain
+    assert torch.equal(eng2.pgd_attack(x.cuda(), y.cuda(), 8 / 255, 2 / 255, 3, random_start=True, seed=2), ref)
