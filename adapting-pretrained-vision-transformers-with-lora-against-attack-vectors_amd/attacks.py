@@ -36,7 +36,9 @@ def _is_imagenet(mean, std) -> bool:
 
 def batched_fgsm_attack(model, images, labels, epsilon, mean, std):
     """clamp(x + eps * sign(dCE/dx), 0, 1) with the model fed (x - mean) / std
-    (whitebox_attacks.py:22-38).  One forward, CE, backward-to-input and one fused step."""
+    (whitebox_attacks.py:22-38).  One forward, CE, backward-to-input and one fused step: exactly one iteration of the PGD
+    loop from x with alpha = eps and no random start (bit-identical: tests/test_hip_fullsize.py::test_fgsm_is_pgd1_...), so
+    it runs as that -- one captured graph, and at the reference's batch of 32 two half-batch chains (vl_pgd_attack)."""
     vit = _unwrap(model)
     eng = vit._engine()
     vit.sync_params()
@@ -44,12 +46,7 @@ def batched_fgsm_attack(model, images, labels, epsilon, mean, std):
     s = [float(v) for v in torch.as_tensor(std).flatten().tolist()]
     eng.set_normalization(m, s)
     x = images.detach().to(device=eng.device, dtype=torch.float32).contiguous()
-    eng.forward(x, normalise=True, train=False)
-    eng.loss_ce(labels)
-    gx, _ = eng.backward(True, False, tuple(x.shape))
-    adv = x.clone()
-    eng.pgd_step(adv, x, gx, epsilon, epsilon, 0.0, 1.0)      # x0 == adv, alpha == eps
-    return adv
+    return eng.pgd_attack(x, labels, float(epsilon), float(epsilon), 1, random_start=False)
 
 
 class _Attack:
@@ -96,7 +93,9 @@ class FGSM(_Attack):
 
     def forward(self, images, labels):
         vit, eng, x = self._prepare(images)
-        eng.forward(x, normalise=self._norm is not None, train=False)
+        if self._norm is not None:            # the PGD loop feeds the model normalised pixels: one iteration of it, alpha = eps
+            return self._finish(eng, eng.pgd_attack(x, labels, float(self.eps), float(self.eps), 1, random_start=False))
+        eng.forward(x, normalise=False, train=False)
         eng.loss_ce(labels)
         gx, _ = eng.backward(True, False, tuple(x.shape))
         adv = x.clone()
