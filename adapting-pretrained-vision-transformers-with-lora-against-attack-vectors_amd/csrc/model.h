@@ -117,6 +117,11 @@ struct vl_model {
     int pgd_chains = 0;           // "pgd_chains" / VITLORA_PGD_CHAINS: 0 = by batch size (2 for 2 <= batch <= 128), 1 = never, 2 = whenever it fits
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // the same two chains behind vl_forward(train = 0) / vl_backward_input (opt-in, "api_chains": the adversarial-patch EoT step runs
+    // through these calls): logits are gathered into the main workspace, vl_loss_ce works on the whole batch, the backward splits again
+    int api_chains = 0;
+    int fwd_chains = 0;           // how the last vl_forward ran (0: one chain in the main workspace; 2: two chains)
+    int chain_B[2] = {0, 0}, chain_cls[2] = {0, 0};
     int64_t n_captures = 0, n_commits = 0;
     int use_graph = 1;
     int resid_epi = 2;    // residual add of the 16-bit stream in the GEMM epilogue (EPI_RESID_H16): 1 = attention output projection, 2 = + fc2, 0 = LayerNorm-side

@@ -634,6 +634,13 @@ static void drop_graphs(vl_model* m) {
     m->graphs.clear();
 }
 
+static int chain_resources(vl_model* m) {
+    if (!m->side_stream) HIPCHK(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
+    if (!m->ev_fork) HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    if (!m->ev_join) HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    return VL_OK;
+}
+
 // Two-chain PGD (model.h): each chain's activations for up to `cb` images, carved behind the main workspace.  carve() fills
 // m->ws, so the chain structs are swapped in while it runs.
 static int chain_images(const vl_model* m, int max_batch) {
@@ -795,8 +802,35 @@ int vl_forward(vl_model* m, const float* x, int batch, int normalise, int train,
     int rc = check_async(m);
     if (rc) return rc;
     if (m->dirty && (rc = vl_lora_commit(m, stream))) return rc;     // never run on stale adapter operands
-    rc = forward_impl(m, x, batch, normalise, train, s);
-    if (rc) return rc;
+    m->fwd_chains = 0;
+    const int b0 = (batch + 1) / 2, b1 = batch - b0;
+    if (m->api_chains && !train && !m->f32 && m->chain_batch > 0 && batch >= 2 && b0 <= m->chain_batch &&
+        batch <= vl_model::CHAIN_MAX_BATCH && batch <= m->ws.max_batch && !capturing(s) && !g_prof) {
+        // two half-batch chains (model.h): chain 0 on the caller's stream, chain 1 on the side stream, logits gathered in the main workspace
+        if ((rc = chain_resources(m))) return rc;
+        float* const main_logits = m->ws.logits;
+        const int64_t img = (int64_t)3 * m->S * m->S;
+        HIPCHK(hipEventRecord(m->ev_fork, s));
+        HIPCHK(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
+        int rcs[2];
+        for (int c = 0; c < 2; ++c) {
+            hipStream_t sc = c ? m->side_stream : s;
+            const int bc = c ? b1 : b0;
+            std::swap(m->ws, m->chain_ws[c]);
+            rcs[c] = forward_impl(m, x + (c ? b0 * img : 0), bc, normalise, 0, sc);
+            float* const cl = m->ws.logits;
+            std::swap(m->ws, m->chain_ws[c]);
+            m->chain_B[c] = bc; m->chain_cls[c] = m->cur_cls_only;
+            if (!rcs[c]) (void)hipMemcpyAsync(main_logits + (size_t)(c ? b0 : 0) * m->C, cl, (size_t)bc * m->C * sizeof(float), hipMemcpyDeviceToDevice, sc);
+        }
+        HIPCHK(hipEventRecord(m->ev_join, m->side_stream));
+        HIPCHK(hipStreamWaitEvent(s, m->ev_join, 0));
+        if (rcs[0] || rcs[1]) { m->cur_B = 0; return rcs[0] ? rcs[0] : rcs[1]; }
+        m->cur_B = batch; m->cur_M = batch * m->T; m->cur_norm = normalise; m->cur_train = 0; m->have_loss = 0; m->fwd_chains = 2;
+    } else {
+        rc = forward_impl(m, x, batch, normalise, train, s);
+        if (rc) return rc;
+    }
     if (logits_out)
         HIPCHK(hipMemcpyAsync(logits_out, m->ws.logits, (size_t)batch * m->C * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (!capturing(s)) return check_launch("vl_forward");
@@ -960,6 +994,33 @@ int vl_set_dlogits(vl_model* m, const float* dlogits, void* stream) {
 static int backward_api(vl_model* m, float* grad_x, float* flat_grad, hipStream_t s) {
     int rc = check_async(m);
     if (rc) return rc;
+    if (m->fwd_chains == 2) {
+        // the forward ran as two chains: so does the backward, each from its slice of the whole batch's dLoss/dlogits
+        if (flat_grad) return fail(VL_ERR_STATE, "vl_backward_lora needs vl_forward(train=1)");
+        if (!m->have_loss) return fail(VL_ERR_STATE, "backward before vl_loss_ce");
+        if ((rc = chain_resources(m))) return rc;
+        const int batch = m->cur_B, b0 = m->chain_B[0];
+        const float* const main_dlogits = m->ws.dlogits;
+        const int64_t img = (int64_t)3 * m->S * m->S;
+        HIPCHK(hipEventRecord(m->ev_fork, s));
+        HIPCHK(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
+        int rcs[2];
+        for (int c = 0; c < 2; ++c) {
+            hipStream_t sc = c ? m->side_stream : s;
+            std::swap(m->ws, m->chain_ws[c]);
+            (void)hipMemcpyAsync(m->ws.dlogits, main_dlogits + (size_t)(c ? b0 : 0) * m->C, (size_t)m->chain_B[c] * m->C * sizeof(float),
+                                 hipMemcpyDeviceToDevice, sc);
+            m->cur_B = m->chain_B[c]; m->cur_cls_only = m->chain_cls[c]; m->have_loss = 1;
+            rcs[c] = backward_impl(m, grad_x ? grad_x + (c ? b0 * img : 0) : nullptr, nullptr, sc);
+            std::swap(m->ws, m->chain_ws[c]);
+        }
+        m->cur_B = batch;
+        HIPCHK(hipEventRecord(m->ev_join, m->side_stream));
+        HIPCHK(hipStreamWaitEvent(s, m->ev_join, 0));
+        if (rcs[0] || rcs[1]) return rcs[0] ? rcs[0] : rcs[1];
+        if (!capturing(s)) return check_launch("vl_backward");
+        return VL_OK;
+    }
     rc = backward_impl(m, grad_x, flat_grad, s);
     if (rc) return rc;
     if (!capturing(s)) return check_launch("vl_backward");
@@ -1137,11 +1198,8 @@ int vl_pgd_attack(vl_model* m, const float* x0, const int64_t* labels, int batch
         m->cur_B = 0;                 // the handle holds no forward of the whole batch: a backward call needs its own forward
         return rc0 ? rc0 : rc1;
     };
-    if (chains == 2) {
-        if (!m->side_stream) HIPCHK(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
-        if (!m->ev_fork) HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-        if (!m->ev_join) HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
-    }
+    m->fwd_chains = 0;
+    if (chains == 2 && (rc = chain_resources(m))) return rc;
     if (steps > 0) {
         if (!m->use_graph || g_prof || g_poison_lds) {
             for (int i = 0; i < steps; ++i)
@@ -1427,6 +1485,8 @@ int vl_debug_set_cus(vl_model* m, int cus) {
 //   "attn_ring" 1 (default): single-pass per-image attention backward; 0: the two-phase form (process-wide switch)
 //   "pgd_chains" 0 (default): vl_pgd_attack runs batches of 2 .. 128 images as two half-batch chains in parallel branches of the
 //               captured iteration; 1: one chain always; 2: two chains whenever the chain workspaces hold the halves
+//   "api_chains" 0 (default); 1: vl_forward(train = 0) and the backward after it run batches of 2 .. 128 images as the same two
+//               chains (the adversarial-patch EoT step uses these calls); vl_debug_tensor then does not see the activations
 //   "poison_lds" 0 (default); 1: every profiled launch is preceded by a kernel that fills every CU's LDS with NaN patterns (test hook)
 int vl_debug_set_option(vl_model* m, const char* name, int value) {
     if (!m || !name) return fail(VL_ERR_ARG, "null argument");
@@ -1436,6 +1496,7 @@ int vl_debug_set_option(vl_model* m, const char* name, int value) {
     else if (!strcmp(name, "attn_ring")) attention32_set_ring(value);        // process-wide
     else if (!strcmp(name, "poison_lds")) g_poison_lds = value ? 1 : 0;      // process-wide test hook (prof.h); attacks then run eagerly
     else if (!strcmp(name, "pgd_chains")) m->pgd_chains = value < 0 ? 0 : value > 2 ? 2 : value;    // 1: set BEFORE vl_plan to save the chain workspaces
+    else if (!strcmp(name, "api_chains")) m->api_chains = value ? 1 : 0;      // vl_forward(train = 0) / vl_backward_input as two half-batch chains (2 .. 128 images)
     else return fail(VL_ERR_ARG, "unknown option %s", name);
     drop_graphs(m);
     return VL_OK;

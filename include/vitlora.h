@@ -289,7 +289,9 @@ int vl_debug_set_gemm_stream(int mode);
  * exact; 0: every row) "fuse_pgd" (1: vl_pgd_attack applies K10 in the patch-gradient epilogue; 0: separate launch) and "pgd_chains" (0, default:
  * vl_pgd_attack runs batches of 2 .. 128 images as two half-batch chains -- one captured iteration each, own activation workspaces
  * carved behind the main one by vl_plan, two streams that meet at the start and the end of the attack; 1: one chain always, set
- * BEFORE vl_plan to save those workspaces; 2: two chains whenever the halves fit).  Results are bit-identical either way. */
+ * BEFORE vl_plan to save those workspaces; 2: two chains whenever the halves fit) and "api_chains" (0, default; 1: vl_forward(train = 0)
+ * and the backward after it run such batches as the same two chains -- the adversarial-patch EoT step goes through these calls;
+ * vl_debug_tensor then does not see the activations).  Results are bit-identical either way. */
 int vl_debug_set_option(vl_model* m, const char* name, int value);
 int vl_debug_set_cus(vl_model* m, int cus);   /* persistent GEMM grid size (diagnostic; default = the device's CU count) */
 

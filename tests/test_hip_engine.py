@@ -696,3 +696,43 @@ def test_two_chain_attack_is_planned_away_when_switched_off_before_the_plan():
     assert torch.equal(eng2.pgd_attack(x.cuda(), y.cuda(), 8 / 255, 2 / 255, 3, random_start=True, seed=2), ref)
     eng2.set_option("pgd_chains", 2)               # asked for after the plan: there is no chain workspace, it stays one chain
     assert torch.equal(eng2.pgd_attack(x.cuda(), y.cuda(), 8 / 255, 2 / 255, 3, random_start=True, seed=2), ref)
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+@pytest.mark.parametrize("image_size,batch", [(64, 2), (64, 5), (224, 3), (224, 32)])
+def test_two_chain_forward_backward_equals_the_single_chain_calls(prec, image_size, batch):
+    """ "api_chains": vl_forward(train = 0) / vl_loss_ce / vl_backward_input with the batch split into two half-batch chains (the
+    adversarial-patch EoT step runs through these calls) -- logits, loss and input gradient are those of the plain calls bit for
+    bit; a train-mode forward, the fp32 mode and a later attack are unaffected."""
+    cfg, w, lora, x, y = make_case(image_size=image_size, batch=batch, r=8)
+    eng = make_engine(cfg, w, lora, precision=prec)
+    ref = []
+    for chains in (0, 1, 0):
+        eng.set_option("api_chains", chains)
+        logits = eng.forward(x.cuda(), normalise=True).clone()
+        loss = eng.loss_ce(y.cuda()).clone()
+        gx, _ = eng.backward(True, False, tuple(x.shape))
+        eng.check()
+        ref.append((logits, loss, gx.clone()))
+    for k in range(3):
+        assert torch.equal(ref[1][k], ref[0][k]) and torch.equal(ref[2][k], ref[0][k]), (prec, image_size, batch, k)
+    eng.set_option("api_chains", 1)
+    # a different batch size next (graph-free path: nothing cached), then a train-mode step and an attack on the same handle
+    h = max(2, batch // 2)
+    l2 = eng.forward(x[:h].cuda(), normalise=True).clone()
+    eng.set_option("api_chains", 0)
+    assert torch.equal(l2, eng.forward(x[:h].cuda(), normalise=True))
+    eng.set_option("api_chains", 1)
+    eng.forward(x.cuda(), normalise=True, train=True)
+    eng.loss_ce(y.cuda())
+    _, gp = eng.backward(False, True)
+    assert torch.isfinite(gp).all()
+    adv = eng.pgd_attack(x.cuda(), y.cuda(), 8 / 255, 2 / 255, 2, random_start=False)
+    eng.set_option("api_chains", 0)
+    assert torch.equal(adv, eng.pgd_attack(x.cuda(), y.cuda(), 8 / 255, 2 / 255, 2, random_start=False))
+    with pytest.raises(Exception):
+        eng.set_option("api_chains", 1)
+        eng.forward(x.cuda(), normalise=True)
+        eng.loss_ce(y.cuda())
+        eng.backward(False, True)          # parameter gradients need a train-mode forward
+    eng.set_option("api_chains", 0)
