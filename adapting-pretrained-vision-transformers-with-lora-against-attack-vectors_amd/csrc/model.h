@@ -111,10 +111,10 @@ struct vl_model {
     // of the one graph (fork / join by events on cap_stream / side_stream) -- a GEMM launch costs about one round more than its
     // tiles (pipeline fill + exposed epilogue), and one chain's ends then meet the other's main loops.  Each chain has its own
     // activation workspace (carved behind the main one for batches up to CHAIN_MAX_BATCH / 2).
-    static constexpr int CHAIN_MAX_BATCH = 128;
+    static constexpr int CHAIN_MAX_BATCH = 191;     // below the batch at which the per-image attention kernels take over (3/4 of 256 CUs): both forms of a batch then use the same kernels
     Workspace chain_ws[2];
     int chain_batch = 0;          // images each chain workspace holds (0: none planned)
-    int pgd_chains = 0;           // "pgd_chains" / VITLORA_PGD_CHAINS: 0 = by batch size (2 for 2 <= batch <= 128), 1 = never, 2 = whenever it fits
+    int pgd_chains = 0;           // "pgd_chains" / VITLORA_PGD_CHAINS: 0 = by batch size (2 for 2 <= batch <= 191), 1 = never, 2 = whenever it fits
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // the same two chains behind vl_forward(train = 0) / vl_backward_input (opt-in, "api_chains": the adversarial-patch EoT step runs

@@ -1483,9 +1483,9 @@ int vl_debug_set_cus(vl_model* m, int cus) {
 //   "fuse_pgd"  1 (default): vl_pgd_attack applies the PGD step inside the patch-gradient GEMM epilogue; 0: gradient to HBM + K10
 //   "resid_epi" 1 (default): the residual add of the 16-bit stream sits in the o / fc2 GEMM epilogue; 0: in the LayerNorm after it
 //   "attn_ring" 1 (default): single-pass per-image attention backward; 0: the two-phase form (process-wide switch)
-//   "pgd_chains" 0 (default): vl_pgd_attack runs batches of 2 .. 128 images as two half-batch chains in parallel branches of the
+//   "pgd_chains" 0 (default): vl_pgd_attack runs batches of 2 .. 191 images as two half-batch chains in parallel branches of the
 //               captured iteration; 1: one chain always; 2: two chains whenever the chain workspaces hold the halves
-//   "api_chains" 0 (default); 1: vl_forward(train = 0) and the backward after it run batches of 2 .. 128 images as the same two
+//   "api_chains" 0 (default); 1: vl_forward(train = 0) and the backward after it run batches of 2 .. 191 images as the same two
 //               chains (the adversarial-patch EoT step uses these calls); vl_debug_tensor then does not see the activations
 //   "poison_lds" 0 (default); 1: every profiled launch is preceded by a kernel that fills every CU's LDS with NaN patterns (test hook)
 int vl_debug_set_option(vl_model* m, const char* name, int value) {
@@ -1496,7 +1496,7 @@ int vl_debug_set_option(vl_model* m, const char* name, int value) {
     else if (!strcmp(name, "attn_ring")) attention32_set_ring(value);        // process-wide
     else if (!strcmp(name, "poison_lds")) g_poison_lds = value ? 1 : 0;      // process-wide test hook (prof.h); attacks then run eagerly
     else if (!strcmp(name, "pgd_chains")) m->pgd_chains = value < 0 ? 0 : value > 2 ? 2 : value;    // 1: set BEFORE vl_plan to save the chain workspaces
-    else if (!strcmp(name, "api_chains")) m->api_chains = value ? 1 : 0;      // vl_forward(train = 0) / vl_backward_input as two half-batch chains (2 .. 128 images)
+    else if (!strcmp(name, "api_chains")) m->api_chains = value ? 1 : 0;      // vl_forward(train = 0) / vl_backward_input as two half-batch chains (2 .. 191 images)
     else return fail(VL_ERR_ARG, "unknown option %s", name);
     drop_graphs(m);
     return VL_OK;

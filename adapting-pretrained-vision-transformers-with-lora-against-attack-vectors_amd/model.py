@@ -82,7 +82,7 @@ class ViTForImageClassification(torch.nn.Module):
         if self._eng is None:
             dev = self._device or torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
             self._eng = Engine(self.arch, self.lora_spec, device=dev, precision=self.precision)
-            # eval-mode forwards (and the backward-to-pixels after them) of 2 .. 128 images run as two half-batch chains on two
+            # eval-mode forwards (and the backward-to-pixels after them) of 2 .. 191 images run as two half-batch chains on two
             # streams -- bit-identical, faster at the reference's batch sizes (evaluate loops, the patch EoT step); train-mode
             # steps are not split (include/vitlora.h: "api_chains")
             self._eng.set_option("api_chains", 1)

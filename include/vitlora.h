@@ -171,7 +171,7 @@ int vl_pgd_init(float* adv, const float* x0, float eps, float lo, float hi, uint
 
 /* torchattacks.PGD(model, eps, alpha, steps, random_start)(images, labels)
  * (whitebox_attacks.py:112-113,170).  One iteration (forward, CE, backward-to-input,
- * fused step) is captured once into a hipGraph and replayed `steps` times (batches of 2 .. 128 images: one graph per
+ * fused step) is captured once into a hipGraph and replayed `steps` times (batches of 2 .. 191 images: one graph per
  * half batch, replayed on `stream` and on an internal stream that is joined before the result is copied out).
  * x0, adv_out: [B,3,S,S] fp32 in [0,1]; adv_out may not alias x0. */
 int vl_pgd_attack(vl_model* m, const float* x0, const int64_t* labels, int batch,
@@ -287,7 +287,7 @@ int vl_debug_set_gemm_pp(int mode);
 int vl_debug_set_gemm_stream(int mode);
 /* Diagnostic switches of one handle: "dead_rows" (1: eval-mode forwards compute the last encoder layer on the CLS rows only,
  * exact; 0: every row) "fuse_pgd" (1: vl_pgd_attack applies K10 in the patch-gradient epilogue; 0: separate launch) and "pgd_chains" (0, default:
- * vl_pgd_attack runs batches of 2 .. 128 images as two half-batch chains -- one captured iteration each, own activation workspaces
+ * vl_pgd_attack runs batches of 2 .. 191 images as two half-batch chains -- one captured iteration each, own activation workspaces
  * carved behind the main one by vl_plan, two streams that meet at the start and the end of the attack; 1: one chain always, set
  * BEFORE vl_plan to save those workspaces; 2: two chains whenever the halves fit) and "api_chains" (0, default; 1: vl_forward(train = 0)
  * and the backward after it run such batches as the same two chains -- the adversarial-patch EoT step goes through these calls;

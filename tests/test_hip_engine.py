@@ -650,7 +650,7 @@ def test_results_do_not_depend_on_what_the_previous_kernel_left_in_lds(prec, att
 @pytest.mark.parametrize("prec", ["f16", "bf16"])
 @pytest.mark.parametrize("image_size,batch", [(64, 2), (64, 5), (224, 3), (224, 32)])
 def test_two_chain_attack_equals_the_single_chain_attack(prec, image_size, batch):
-    """vl_pgd_attack runs batches of 2 .. 128 images as TWO half-batch chains (own activation workspaces, one captured iteration
+    """vl_pgd_attack runs batches of 2 .. 191 images as TWO half-batch chains (own activation workspaces, one captured iteration
     each, two streams that meet at the start and the end of the attack: DESIGN.md section 3.7).  Images are independent, so the
     result is the single-chain result bit for bit -- for odd batches (3 + 2), with and without the random start, graph replay and
     eager, and whatever the option says; one capture event serves the whole attack."""

@@ -2,7 +2,8 @@
 """Small batches: does the PGD attack gain from running as TWO independent half-batch chains on two streams, so that the ends of
 one chain's kernels (pipeline fill, exposed epilogue: about one round per GEMM launch) meet the middles of the
 other's?  Arms per batch B, alternating in one process:  single = one handle, batch B;  dual = two handles, batch B/2 each, two
-streams, launched back to back.     python tools/dual_chain_small.py 64 32"""
+streams, launched back to back (CHAINS=n in the environment: n handles of B/n).  This is the experiment behind the two-chain form
+vl_pgd_attack now has built in ("pgd_chains"); the handles here run with that switched off.     python tools/dual_chain_small.py 64 32"""
 import importlib, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,6 +20,7 @@ def make():
     for (i, t), (A, Bm) in syn.random_lora(arch, 8, T, seed=1).items():
         e.param(i, t, "A").copy_(A); e.param(i, t, "B").copy_(Bm)
     e.commit()
+    e.set_option("pgd_chains", 1)          # the library's own two-chain form off: this probe compares plain single-chain handles
     return e
 
 NCH = int(os.environ.get("CHAINS", 2))

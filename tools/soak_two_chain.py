@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak of the two-chain attack (vl_pgd_attack at batches of 2 .. 128 images: two half-batch graphs on two streams): the same
+"""Soak of the two-chain attack (vl_pgd_attack at batches of 2 .. 191 images: two half-batch graphs on two streams): the same
 attack N times in one process, alternating batch sizes (graph cache, chain workspaces re-used), must give the same pixels every
 time and the pixels of the one-chain attack.     python tools/soak_two_chain.py [repeats]"""
 import importlib, os, sys
