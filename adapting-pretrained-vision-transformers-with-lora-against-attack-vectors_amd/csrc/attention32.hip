@@ -59,6 +59,25 @@ __device__ unsigned long long g_attn_stamps[8192 * 8 * 8];
 
 namespace {
 
+// VL_ATTN_NT=1: q / k / v / dO / O are streamed with non-temporal loads (LDS-DMA aux bit 1 and the row-fragment loads); an
+// A/B switch (tools/build_variant.sh).  Measured in round 5 and not kept: backward 2.22 -> 2.51 ms, forward 0.85 -> 1.05 ms per
+// iteration (the operands were written by the GEMM before and are Infinity-Cache hits; profiles/r05_nt_loads_ab.txt)
+#ifndef VL_ATTN_NT
+#define VL_ATTN_NT 0
+#endif
+__device__ __forceinline__ void glds16a(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc), LDS_PTR(lds_wave_base), 16, 0, VL_ATTN_NT ? 2 : 0);
+}
+__device__ __forceinline__ h16x8 ld_attn(const h16* p) {
+#if VL_ATTN_NT
+    return __builtin_nontemporal_load((const h16x8*)p);
+#else
+    return *(const h16x8*)p;
+#endif
+}
+
+
+
 constexpr int HD = 64;
 #define TPAD(t) ((double)(((t) + 31) / 32 * 32))      // executed-FLOP accounting: the kernels work on 32-token tiles
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -137,7 +156,7 @@ __device__ __forceinline__ void stage_glds(h16* img, const h16* src, int ld, int
     for (int g = w; g < ROWS / 8; g += NW) {
         const int r = g * 8 + lr;
         const int rs = r < T ? r : T - 1;
-        glds16(src + (size_t)rs * ld + ((lc ^ swz(r)) << 3), img + g * 8 * HD);
+        glds16a(src + (size_t)rs * ld + ((lc ^ swz(r)) << 3), img + g * 8 * HD);
     }
 }
 
@@ -317,8 +336,8 @@ __global__ __launch_bounds__(512) void attn_bwd32_kernel(const h16* __restrict__
     for (int j = 0; j < NPASS; ++j) {
         const int idx = tid + j * 512, r = idx >> 3, cc = idx & 7;
         const int rc = r < T ? r : T - 1;                  // clamped: every load is valid, masked below
-        pdv[j] = *(const h16x8*)(dobase + (size_t)rc * D + cc * 8);
-        pov[j] = *(const h16x8*)(obase + (size_t)rc * D + cc * 8);
+        pdv[j] = ld_attn(dobase + (size_t)rc * D + cc * 8);
+        pov[j] = ld_attn(obase + (size_t)rc * D + cc * 8);
         plse[j] = lse2[((size_t)b * H + hd) * T + rc];
     }
     STAMP(7);
@@ -561,7 +580,7 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_fwd_img_kernel(const h16*
     h16x8 qf[4];
     if (!loader && active) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const h16x8*)(base + (size_t)qc * ld + 8 * h + 16 * ks);
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = ld_attn(base + (size_t)qc * ld + 8 * h + 16 * ks);
     }
     __syncthreads();
 
@@ -731,7 +750,7 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_fwd_img_kernel(const h16*
             FSTAMP(hd, 3);
             if (hd + 1 < H) {                                  // next head's query fragments fly under the epilogue
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const h16x8*)(base + (size_t)qc * ld + (hd + 1) * HD + 8 * h + 16 * ks);
+                for (int ks = 0; ks < 4; ++ks) qf[ks] = ld_attn(base + (size_t)qc * ld + (hd + 1) * HD + 8 * h + 16 * ks);
             }
             l += __shfl_xor(l, 32, 64);
             const float inv = 1.f / l;
@@ -830,9 +849,9 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_bwd_img_kernel(const h16*
     auto fetch_a = [&](int hd) {             // phase A operands of head hd for this lane's query
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            fa[ks] = *(const h16x8*)(base + (size_t)tokc * ld + hd * HD + 8 * h + 16 * ks);
-            fb[ks] = *(const h16x8*)(dobase + (size_t)tokc * D + hd * HD + 8 * h + 16 * ks);
-            fo_[ks] = *(const h16x8*)(obase + (size_t)tokc * D + hd * HD + 8 * h + 16 * ks);
+            fa[ks] = ld_attn(base + (size_t)tokc * ld + hd * HD + 8 * h + 16 * ks);
+            fb[ks] = ld_attn(dobase + (size_t)tokc * D + hd * HD + 8 * h + 16 * ks);
+            fo_[ks] = ld_attn(obase + (size_t)tokc * D + hd * HD + 8 * h + 16 * ks);
         }
         lse_own = lse2[((size_t)b * H + hd) * T + tokc];
     };
@@ -1106,8 +1125,8 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_bwd_ring_kernel(const h16
             const int t = blk * 32 + c, tc = t < T ? t : T - 1;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                rd8[ks] = *(const h16x8*)(dobase + (size_t)tc * D + hd * HD + 8 * h + 16 * ks);
-                ro8[ks] = *(const h16x8*)(obase + (size_t)tc * D + hd * HD + 8 * h + 16 * ks);
+                rd8[ks] = ld_attn(dobase + (size_t)tc * D + hd * HD + 8 * h + 16 * ks);
+                ro8[ks] = ld_attn(obase + (size_t)tc * D + hd * HD + 8 * h + 16 * ks);
             }
             rlse = lse2[((size_t)b * H + hd) * T + tc];
         };
@@ -1166,7 +1185,7 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_bwd_ring_kernel(const h16
                         for (int g = i * per; g < (i + 1) * per && g < NG; ++g) {
                             const int r = g * 8 + lr;
                             const int rs = r < T ? r : T - 1;
-                            glds16(src + (size_t)rs * ld + ((lc ^ swz(r)) << 3), img + g * 8 * HD);
+                            glds16a(src + (size_t)rs * ld + ((lc ^ swz(r)) << 3), img + g * 8 * HD);
                         }
                     }
                 }
@@ -1219,7 +1238,7 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_bwd_ring_kernel(const h16
     }
     h16x8 fb[4];                            // own v rows (B operand of dP); own k rows are re-read from the K image (registers are short)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) fb[ks] = *(const h16x8*)(base + (size_t)tokc * ld + 2 * D + 8 * h + 16 * ks);
+    for (int ks = 0; ks < 4; ++ks) fb[ks] = ld_attn(base + (size_t)tokc * ld + 2 * D + 8 * h + 16 * ks);
     if (w >= 4 && RING_PRIO) __builtin_amdgcn_s_setprio(1);
     LDS_BARRIER();
 
@@ -1363,7 +1382,7 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void attn_bwd_ring_kernel(const h16
             // next head's own v rows first: ahead of this head's stores in the wave's memory queue
             if (hd + 1 < H) {
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) fb[ks] = *(const h16x8*)(base + (size_t)tokc2 * ld + 2 * D + (hd + 1) * HD + 8 * h2 + 16 * ks);
+                for (int ks = 0; ks < 4; ++ks) fb[ks] = ld_attn(base + (size_t)tokc2 * ld + 2 * D + (hd + 1) * HD + 8 * h2 + 16 * ks);
             }
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)

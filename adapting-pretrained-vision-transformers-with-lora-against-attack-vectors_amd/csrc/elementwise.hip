@@ -397,6 +397,19 @@ __device__ __forceinline__ void lora_down_row16(const h16x8 (&v)[NV], const h16*
     if (live) *(h16x2*)(out_row + 2 * li) = h16x2{f2h(o0), f2h(o1)};
 }
 
+// Streamed 16-byte loads of the 16-bit LayerNorm kernels (every byte of x / dh / the gradient stream is used once per pass).
+// VL_LN_NT: 1 = non-temporal loads (round 5: K10 gained 20 % from them, tools/k10_sweep.hip), 0 = plain loads.
+#ifndef VL_LN_NT
+#define VL_LN_NT 1
+#endif
+__device__ __forceinline__ h16x8 ld_stream8(const h16* p) {
+#if VL_LN_NT
+    return __builtin_nontemporal_load((const h16x8*)p);
+#else
+    return *(const h16x8*)p;
+#endif
+}
+
 template <int NV, int NG>
 __global__ __launch_bounds__(256) void layernorm_fwd16_kernel(const h16* __restrict__ x, h16* __restrict__ h,
                                                               float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -425,10 +438,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd16_kernel(const h16* __restr
             const int c = li + i * 32;
             v[i][0] = v[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (c < nc) {
-                const h16x8 xv = *(const h16x8*)(x + off + c * 8);
+                const h16x8 xv = ld_stream8(x + off + c * 8);
                 if (delta) {
                     // residual add fused in: x' = round16(x + delta) (delta = the h16 output of the projection before it)
-                    const h16x8 dl = *(const h16x8*)(delta + off + c * 8);
+                    const h16x8 dl = ld_stream8(delta + off + c * 8);
                     h16x8 xr;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
@@ -482,7 +495,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd16_kernel(const h16* __restr
         }
         if constexpr (NG > 0) lora_down_row16<NV, NG>(vb, sP, D, nc, li, half, t + (int64_t)(live ? row : 0) * 64, live);
     }
-    if (sat && err) *err = 2;
+    if (sat && err) *err = 4;      // a FORWARD overflow of the 16-bit residual stream (its own message: round-4 ADVICE)
 }
 
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dh * gamma, xhat = (x - mean) * rstd; `dres` is read and
@@ -517,9 +530,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd16_kernel(const h16* __restr
             g[i][0] = g[i][1] = xh[i][0] = xh[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             rv[i] = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
             if (c < nc) {
-                const h16x8 d = *(const h16x8*)(dh + off + c * 8);
-                const h16x8 xv = *(const h16x8*)(x + off + c * 8);
-                rv[i] = *(const h16x8*)(dres + off + c * 8);
+                const h16x8 d = ld_stream8(dh + off + c * 8);
+                const h16x8 xv = ld_stream8(x + off + c * 8);
+                rv[i] = ld_stream8(dres + off + c * 8);
                 const f32x4 g0 = *(const f32x4*)(gamma + c * 8), g1 = *(const f32x4*)(gamma + c * 8 + 4);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -696,23 +709,41 @@ __global__ void classifier_grad_kernel(const float* __restrict__ dlogits, const 
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ float sgn(float g) { return (g > 0.f) ? 1.f : ((g < 0.f) ? -1.f : 0.f); }
 
+// Access shape (round 5, tools/k10_sweep.hip on MI355X, 616.6 MB per launch): the three input streams are read with
+// NON-TEMPORAL 16-byte loads, two vectors per thread in flight, plain stores: 92 us = 6.7 TB/s = 0.84 of the 8 TB/s peak
+// (plain loads, rounds 1-4: 112-119 us = 0.65-0.69; a float4 copy reaches 5.5 TB/s on the same box; non-temporal STORES lose
+// the gain again: 106 us).  Every byte is used once, so nothing is lost by not keeping the lines.
 __global__ __launch_bounds__(256) void pgd_step_kernel(float* __restrict__ adv, const float* __restrict__ x0,
                                                        const float* __restrict__ grad, float eps, float alpha,
                                                        float lo, float hi, int64_t n4, int64_t n, int* __restrict__ err) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const f32x4 a = *(const f32x4*)(adv + i * 4);
-        const f32x4 x = *(const f32x4*)(x0 + i * 4);
-        const f32x4 g = *(const f32x4*)(grad + i * 4);
-        if (err && !(fabsf(g[0]) < INFINITY && fabsf(g[1]) < INFINITY && fabsf(g[2]) < INFINITY && fabsf(g[3]) < INFINITY)) *err = 2;
-        f32x4 o;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += 2 * stride) {
+        const int64_t j = i + stride;
+        const bool two = j < n4;
+        const f32x4 a0 = __builtin_nontemporal_load((const f32x4*)adv + i);
+        const f32x4 x0v = __builtin_nontemporal_load((const f32x4*)x0 + i);
+        const f32x4 g0 = __builtin_nontemporal_load((const f32x4*)grad + i);
+        f32x4 a1 = a0, x1v = x0v, g1 = g0;
+        if (two) {
+            a1 = __builtin_nontemporal_load((const f32x4*)adv + j);
+            x1v = __builtin_nontemporal_load((const f32x4*)x0 + j);
+            g1 = __builtin_nontemporal_load((const f32x4*)grad + j);
+        }
+        bool bad = false;
+        f32x4 o0, o1;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float t = a[k] + alpha * sgn(g[k]);
-            const float d = fminf(fmaxf(t - x[k], -eps), eps);
-            o[k] = fminf(fmaxf(x[k] + d, lo), hi);
+            bad |= !(fabsf(g0[k]) < INFINITY) | !(fabsf(g1[k]) < INFINITY);
+            const float t0 = a0[k] + alpha * sgn(g0[k]);
+            const float d0 = fminf(fmaxf(t0 - x0v[k], -eps), eps);
+            o0[k] = fminf(fmaxf(x0v[k] + d0, lo), hi);
+            const float t1 = a1[k] + alpha * sgn(g1[k]);
+            const float d1 = fminf(fmaxf(t1 - x1v[k], -eps), eps);
+            o1[k] = fminf(fmaxf(x1v[k] + d1, lo), hi);
         }
-        *(f32x4*)(adv + i * 4) = o;
+        if (err && bad) *err = 2;
+        *((f32x4*)adv + i) = o0;
+        if (two) *((f32x4*)adv + j) = o1;
     }
     // tail (n not a multiple of 4)
     const int64_t i = n4 * 4 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1053,7 +1084,7 @@ void k_pgd_step(float* adv, const float* x0, const float* grad, float eps, float
                 hipStream_t s, int* err) {
     ProfScope prof_("pgd_step_kernel", 0.0, (double)n * 16.0, s);
     const int64_t n4 = n / 4;
-    hipLaunchKernelGGL(pgd_step_kernel, dim3(nblk(n4 > 0 ? n4 : 1, 256, 2048)), dim3(256), 0, s, adv, x0, grad, eps,
+    hipLaunchKernelGGL(pgd_step_kernel, dim3(nblk(n4 > 0 ? (n4 + 1) / 2 : 1, 256, 8192)), dim3(256), 0, s, adv, x0, grad, eps,
                        alpha, lo, hi, n4, n, err);
 }
 void k_zero(void* p, size_t bytes, hipStream_t s) {

@@ -288,8 +288,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs p, int ntil
 #pragma unroll
             for (int i = 0; i < 2 * MI; ++i) {
                 const h16* zs = (const h16*)p.R + (size_t)(bm * BM + wm * (BM / 2) + i * 16 + fr) * p.ldr + n0;
-                rz[i][0] = *(const h16x8*)zs;
-                rz[i][1] = *(const h16x8*)(zs + 8);
+                rz[i][0] = ld_once((const h16x8*)zs);
+                rz[i][1] = ld_once((const h16x8*)(zs + 8));
             }
 #pragma unroll
             for (int i = 0; i < 2 * MI; ++i) {

@@ -3,7 +3,24 @@
 #pragma once
 #include "gemm.h"
 
+// Operands an epilogue reads exactly once (the saved gelu'(z), the residual-stream row, adv / x0 of the fused PGD step):
+// VL_EPI_NT=1 streams them with non-temporal loads.  Measured in round 5 (same box, alternating, profiles/r05_nt_loads_ab.txt)
+// and NOT kept: inside the PGD iteration these operands are served from the Infinity Cache (adv / x0 stay resident between
+// iterations, gelu'(z) and the stream rows were written a few kernels earlier) and the non-temporal form loses those hits
+// (patch-gradient + PGD-step GEMM 0.19 -> 0.26 ms, GELU-backward GEMM +2 %, 527 -> 521 img/s).  The standalone K10, whose
+// 617 MB do not fit the cache, gains 20 % from the same loads (elementwise.hip).
+#ifndef VL_EPI_NT
+#define VL_EPI_NT 0
+#endif
 namespace VLNS {
+template <typename V> __device__ __forceinline__ V ld_once(const V* p) {
+#if VL_EPI_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 
 // erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7): one v_rcp + one v_exp instead of the
 // branchy libm erff; the shared exp(-x^2/2) also gives the Gaussian pdf for gelu'.
@@ -97,8 +114,8 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
             if constexpr (EPI == EPI_PATCH_PGD) {
                 // K10 on the gradient while it is still in registers (the same fp32 operations as pgd_step_kernel, in the
                 // same order: bit-identical to the two-kernel form)
-                const f32x4 a = *(const f32x4*)dst;
-                const f32x4 x = *(const f32x4*)((const float*)p.R + at);
+                const f32x4 a = ld_once((const f32x4*)dst);
+                const f32x4 x = ld_once((const f32x4*)((const float*)p.R + at));
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float sg = (o[k] > 0.f) ? 1.f : ((o[k] < 0.f) ? -1.f : 0.f);
@@ -191,10 +208,10 @@ __device__ __forceinline__ void epilogue_row16(const GemmArgs& p, int m, int n0,
     } else if constexpr (EPI == EPI_GELU_BWD) {
         // R = gelu'(z) saved by the forward epilogue
         const h16* zs = (const h16*)p.R + (size_t)m * p.ldr + n0;
-        epilogue_gelu_bwd16(p, m, n0, v, *(const h16x8*)zs, *(const h16x8*)(zs + 8));
+        epilogue_gelu_bwd16(p, m, n0, v, ld_once((const h16x8*)zs), ld_once((const h16x8*)(zs + 8)));
     } else if constexpr (EPI == EPI_RESID_H16) {
         const h16* rs = (const h16*)p.R + (size_t)m * p.ldr + n0;
-        epilogue_resid16(p, m, n0, v, *(const h16x8*)rs, *(const h16x8*)(rs + 8));
+        epilogue_resid16(p, m, n0, v, ld_once((const h16x8*)rs), ld_once((const h16x8*)(rs + 8)));
     } else if constexpr (EPI == EPI_NONE) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) asm volatile("" ::"v"(v[q]));

@@ -73,6 +73,16 @@ __device__ __forceinline__ f32x4 gload16(const void* ptr) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(ptr) : "memory");
     return v;
 }
+// the same for an operand that is read exactly once (saved gelu'(z), residual-stream rows): non-temporal (gemm_epi.h, VL_EPI_NT)
+__device__ __forceinline__ f32x4 gload16_once(const void* ptr) {
+    f32x4 v;
+#if VL_EPI_NT
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(v) : "v"(ptr) : "memory");
+#else
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(ptr) : "memory");
+#endif
+    return v;
+}
 // the same for a block's registers alone (BC: no bias registers)
 template <int N, int NB>
 __device__ __forceinline__ void wait_dep1(f32x4 (&b)[4]) {
@@ -267,8 +277,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
         const int m = bm * BM + c * 16 + fr, n0 = bn * BN + wn * 64 + fg * 16;
         if constexpr (EPI == EPI_GELU_BWD || EPI == EPI_RESID_H16) {
             const h16* zs = (const h16*)p.R + (size_t)m * p.ldr + n0;
-            pre[c & 1][0] = gload16(zs);
-            pre[c & 1][1] = gload16(zs + 8);
+            pre[c & 1][0] = gload16_once(zs);
+            pre[c & 1][1] = gload16_once(zs + 8);
         }
     };
     auto apply_block = [&](int tile, auto cc) {

@@ -95,9 +95,14 @@ void k_patch_overlay_bwd(const float* g, const float* mats, const float* persp, 
 void k_clamp(float* x, float lo, float hi, int64_t n, hipStream_t s);
 
 // lora_grad.hip
-// dB[n][j] (+)= sum_m dy[m][n] * t[m][j] ; dA[j][k] (+)= sum_m u[m][j] * x[m][k]  (fp32 outputs)
+// dB[n][j] = sum_m dy[m][n] * t[m][j] ; dA[j][k] = sum_m u[m][j] * x[m][k]  (fp32 outputs), deterministic (round 5):
+// the token rows are cut into lora_wgrad_chunks(M) chunks; chunk c STORES its partial block at out + c * chunk_stride
+// (a slab of per-chunk copies of the flat gradient) and k_reduce_chunks sums the copies in chunk order -- no atomics.
 // inv_gscale: device pointer to the factor that undoes the fp16 gradient scale (element 0 is used; nullptr = 1)
+int lora_wgrad_chunk(int M);      // token rows per chunk: >= 512, at most 32 chunks
+int lora_wgrad_chunks(int M);
 void k_lora_wgrad(const h16* L, int ldl, int ncols_l, const h16* Rm, int ldr, int ncols_r, int M, float scale,
-                  float* out, int ldo, int transpose_out, const float* inv_gscale, hipStream_t s);
+                  float* out, int ldo, int transpose_out, const float* inv_gscale, int64_t chunk_stride, hipStream_t s);
+void k_reduce_chunks(const float* slab, float* out, int64_t n, int chunks, int64_t stride, hipStream_t s);
 
 }  // namespace VLNS

@@ -1,14 +1,23 @@
 // Model handle, packed weights and workspace of libvitlora_hip.so, shared by the API file
 // (vitlora.hip: 16-bit operand path) and the fp32 parity path (vitlora_f32.hip).
 #pragma once
+#include <cstddef>
 #include <string>
 #include <vector>
 
+#include "common.h"
+// The handle type exists once per build of the 16-bit path (h16 = _Float16 / __bf16 pointer members): the tag itself is renamed
+// (vl_model_f16 / vl_model_bf16) and every h16-typed struct below lives in the build's namespace, so no two translation units
+// define one name differently (round-4 ADVICE: one-definition rule).  api_dispatch.cpp sees the opaque ABI type only and reads
+// the precision through the vl_config the handle starts with (static_assert below).
+#define vl_model VL_API(vl_model)
 #include "../../include/vitlora.h"
 #include "kernels.h"
 
 enum { LQKV = 0, LO = 1, LFC1 = 2, LFC2 = 3 };
 static const uint32_t kTargetBits[6] = {VL_T_Q, VL_T_K, VL_T_V, VL_T_O, VL_T_FC1, VL_T_FC2};
+
+namespace VLNS {
 
 struct Slot {           // one adapted module inside a fused projection
     int target_idx;     // 0..5 (q,k,v,o,fc1,fc2)
@@ -57,6 +66,7 @@ struct Workspace {
     h16 *dres_h;                     // 16-bit path: THE residual-gradient stream, updated in place, A operand of the dgrad GEMMs
     h16 *dh, *dctx, *dqkv, *dz, *u;
     h16* xd;                         // train mode: dropout(x) of the current LoRA branch / dgrad temporary [Mpad, MLP]
+    float* wg_slab;                  // train mode: [lora_wgrad_chunks(max rows)][flat LoRA elements] per-chunk copies of the LoRA gradient (lora_grad.hip)
     float* grad_img;                 // [max_batch, 3, S, S] for vl_pgd_attack
     // last layer on CLS rows only (cls_path.hip): compact [Bc = round_up(B, 128), .] buffers, 16-bit operand path
     struct Cls {
@@ -83,6 +93,11 @@ struct GraphEntry {
     hipGraphExec_t exec1;     // chains == 2: the second half-batch's iteration (launched on the side stream)
 };
 
+}  // namespace VLNS
+
+// what the handle-less entry points (vl_adam_step: fp16 build only) need to know about a live handle of EITHER build
+struct VlFlatRecord { void* model; float* flat; int64_t flat_n; int* dirty; int** err_flag; };
+
 struct vl_model {
     vl_config cfg;
     int D, L, H, MLP, S, P, G, NP, T, C, PK;   // PK = 3*P*P
@@ -94,25 +109,25 @@ struct vl_model {
     h16 *Wpe = nullptr, *WpeT = nullptr;
     float* Wpe_f32 = nullptr;                   // fp32 mode
     float *bpe = nullptr, *cls = nullptr, *pos = nullptr, *lnf_g = nullptr, *lnf_b = nullptr;
-    std::vector<Layer> layers;
+    std::vector<VLNS::Layer> layers;
     std::vector<void*> allocs;
     // flat trainable parameters: [layer][target]{A,B} ..., classifier W, classifier b
     float* flat = nullptr;
     int64_t flat_n = 0, cls_w_off = 0, cls_b_off = 0;
     int dirty = 1;                              // flat parameters changed since the last vl_lora_commit
-    Workspace ws;
+    VLNS::Workspace ws;
     // state of the last forward
     int cur_B = 0, cur_M = 0, cur_norm = 0, cur_train = 0, have_loss = 0;
     uint64_t drop_seed = 0x5eed, drop_base = 0x5eed, drop_calls = 0;   // LoRA dropout: seed of the last train-mode forward
     // PGD graph cache (one executable graph per (batch, eps, alpha); staging buffers make it pointer-independent)
-    std::vector<GraphEntry> graphs;
+    std::vector<VLNS::GraphEntry> graphs;
     hipStream_t cap_stream = nullptr;
     // vl_pgd_attack at small batches (round 4): the batch runs as TWO independent half-batch chains, captured as parallel branches
     // of the one graph (fork / join by events on cap_stream / side_stream) -- a GEMM launch costs about one round more than its
     // tiles (pipeline fill + exposed epilogue), and one chain's ends then meet the other's main loops.  Each chain has its own
     // activation workspace (carved behind the main one for batches up to CHAIN_MAX_BATCH / 2).
     static constexpr int CHAIN_MAX_BATCH = 191;     // below the batch at which the per-image attention kernels take over (3/4 of 256 CUs): both forms of a batch then use the same kernels
-    Workspace chain_ws[2];
+    VLNS::Workspace chain_ws[2];
     int chain_batch = 0;          // images each chain workspace holds (0: none planned)
     int pgd_chains = 0;           // "pgd_chains" / VITLORA_PGD_CHAINS: 0 = by batch size (2 for 2 <= batch <= 191), 1 = never, 2 = whenever it fits
     hipStream_t side_stream = nullptr;
@@ -137,6 +152,8 @@ struct vl_model {
     float mean[3] = {0.485f, 0.456f, 0.406f};   // get_normalization, Utils.py:92-93
     float stdv[3] = {0.229f, 0.224f, 0.225f};
 };
+
+static_assert(offsetof(vl_model, cfg) == 0, "api_dispatch.cpp reads the precision through the vl_config the handle starts with");
 
 // helpers defined in vitlora.hip
 int vl_fail(int code, const char* fmt, ...);

@@ -150,14 +150,64 @@ __global__ __launch_bounds__(256) void patch_overlay_kernel(const float* __restr
     }
 }
 
-// d(patch)[c][r][s] += sum over pixels g[b][c][y][x] * M' * (affine bilinear weight) * (resize bilinear weight).
-// One workgroup per (image, band of rows): sums in an LDS copy of the patch gradient, then one global atomic per entry.
+// d(patch)[c][r][s] = sum over pixels g[b][c][y][x] * M' * (affine bilinear weight) * (resize bilinear weight).
+// DETERMINISTIC (round 5; rounds 1-4 summed with float atomics, whose order -- and so the last bits of a few entries -- changed
+// from run to run).  Two launches:
+//   1. patch_grad_max_kernel: the largest |g * M'| over the pixels the patch covers (atomicMax on the bit pattern of a
+//      non-negative float: order-independent);
+//   2. patch_overlay_bwd_kernel, one workgroup per (image, band of rows): every contribution is converted to 64-bit FIXED POINT
+//      whose unit is chosen from that maximum so that even the sum of ALL contributions of the call cannot leave 63 bits
+//      (|contribution| <= max < 2^e; at most 2^cb contributions; unit 2^(e + cb - 62): >= 2^-35 of the largest pixel gradient at
+//      batch 128, whatever the gradient's magnitude) and summed with INTEGER atomics -- in an LDS copy of the patch gradient,
+//      then one 64-bit global atomic per touched entry into a scratch image.  Integer addition is associative: the result does
+//      not depend on the order in which lanes and workgroups arrive.  The workgroup that arrives last converts the scratch image
+//      to fp32, writes the result and leaves the scratch zeroed for the next call.
+// A non-finite pixel gradient turns the whole result into NaN (the backward's non-finite flag has fired upstream in that case).
+constexpr int PS_MAX = 64;                               // patch_args_ok (vitlora.hip)
+__device__ unsigned long long g_patch_acc[3 * PS_MAX * PS_MAX];     // zero between calls; calls on one device are stream-ordered by the caller
+__device__ unsigned g_patch_arrived, g_patch_poison, g_patch_max_bits;
+
+__global__ __launch_bounds__(256) void patch_grad_max_kernel(const float* __restrict__ g, const float* __restrict__ mats,
+                                                             const float* __restrict__ persp, int S, int ps, int circle, int bands) {
+    const int b = blockIdx.x / bands, band = blockIdx.x - b * bands;
+    const int rows = (S + bands - 1) / bands;
+    const int y0 = band * rows, y1 = min(S, y0 + rows);
+    const float* m = mats + b * 6;
+    const float* q = persp ? persp + b * 8 : nullptr;
+    float mx = 0.f;
+    unsigned bad = 0u;
+    for (int t = y0 * S + threadIdx.x; t < y1 * S; t += 256) {
+        const int x = t % S, y = t / S;
+        const Warp wp = warp_of(m, x, y, S);
+        const int nu = (int)nearbyintf(wp.u), nv = (int)nearbyintf(wp.v);
+        if (nu < 0 || nu >= S || nv < 0 || nv >= S) continue;
+        const float mk = mask1_at(q, nv, nu, ps, S, circle);
+        if (mk == 0.f) continue;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = fabsf(g[(((int64_t)b * 3 + c) * S + y) * S + x] * mk);
+            if (!(v < INFINITY)) bad = 1u; else mx = fmaxf(mx, v);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(&g_patch_max_bits, __float_as_uint(mx));
+    if (bad) atomicOr(&g_patch_poison, 1u);
+}
+
 __global__ __launch_bounds__(256) void patch_overlay_bwd_kernel(const float* __restrict__ g, const float* __restrict__ mats,
                                                                 const float* __restrict__ persp, float* __restrict__ dpatch,
-                                                                int S, int ps, int circle, int bands) {
-    extern __shared__ float acc[];        // [3][ps][ps]
+                                                                int S, int ps, int circle, int bands, int count_bits) {
+    extern __shared__ unsigned long long acc[];        // [3][ps][ps] fixed point
+    __shared__ unsigned s_last;
     const int n = 3 * ps * ps;
-    for (int i = threadIdx.x; i < n; i += 256) acc[i] = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc[i] = 0ull;
+    // the call's fixed-point unit: max < 2^e (frexp exponent), every contribution is at most max in magnitude
+    const float gmax = __uint_as_float(__hip_atomic_load(&g_patch_max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    int e = 0;
+    (void)frexpf(gmax, &e);
+    e = max(e, -90);                                     // keeps 2^(62 - cb - e) inside fp32
+    const float to_fix = ldexpf(1.f, 62 - count_bits - e);
     __syncthreads();
     const int b = blockIdx.x / bands, band = blockIdx.x - b * bands;
     const int rows = (S + bands - 1) / bands;
@@ -165,7 +215,10 @@ __global__ __launch_bounds__(256) void patch_overlay_bwd_kernel(const float* __r
     const float* m = mats + b * 6;
     const float* q = persp ? persp + b * 8 : nullptr;
     const float ratio = (float)ps / (float)S;
-    for (int t = y0 * S + threadIdx.x; t < y1 * S; t += 256) {
+    auto fix_add = [&](unsigned long long* p, float v) {
+        atomicAdd(p, (unsigned long long)__float2ll_rn(v * to_fix));      // two's complement: signed sums wrap correctly
+    };
+    for (int t = y0 * S + threadIdx.x; gmax > 0.f && t < y1 * S; t += 256) {
         const int x = t % S, y = t / S;
         const Warp wp = warp_of(m, x, y, S);
         const int nu = (int)nearbyintf(wp.u), nv = (int)nearbyintf(wp.v);
@@ -174,7 +227,10 @@ __global__ __launch_bounds__(256) void patch_overlay_bwd_kernel(const float* __r
         if (mk == 0.f) continue;
         float gv[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) gv[c] = g[(((int64_t)b * 3 + c) * S + y) * S + x] * mk;
+        for (int c = 0; c < 3; ++c) {
+            gv[c] = g[(((int64_t)b * 3 + c) * S + y) * S + x] * mk;
+            if (!(fabsf(gv[c]) < INFINITY)) gv[c] = 0.f;          // counted by the first launch: the result is NaN anyway
+        }
         const float fu = floorf(wp.u), fv = floorf(wp.v);
         const int u0 = (int)fu, v0 = (int)fv;
         const float au = wp.u - fu, av = wp.v - fv;
@@ -191,19 +247,33 @@ __global__ __launch_bounds__(256) void patch_overlay_bwd_kernel(const float* __r
                     const Tap ty = resize_tap(pt.v[k], ps, ratio), tx = resize_tap(pt.u[k], ps, ratio);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        float* pc = acc + c * ps * ps;
+                        unsigned long long* pc = acc + c * ps * ps;
                         const float gw = gv[c] * wk;
-                        atomicAdd(pc + ty.i0 * ps + tx.i0, gw * ty.w0 * tx.w0);
-                        atomicAdd(pc + ty.i0 * ps + tx.i1, gw * ty.w0 * tx.w1);
-                        atomicAdd(pc + ty.i1 * ps + tx.i0, gw * ty.w1 * tx.w0);
-                        atomicAdd(pc + ty.i1 * ps + tx.i1, gw * ty.w1 * tx.w1);
+                        fix_add(pc + ty.i0 * ps + tx.i0, gw * ty.w0 * tx.w0);
+                        fix_add(pc + ty.i0 * ps + tx.i1, gw * ty.w0 * tx.w1);
+                        fix_add(pc + ty.i1 * ps + tx.i0, gw * ty.w1 * tx.w0);
+                        fix_add(pc + ty.i1 * ps + tx.i1, gw * ty.w1 * tx.w1);
                     }
                 }
             }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += 256)
-        if (acc[i] != 0.f) atomicAdd(dpatch + i, acc[i]);
+        if (acc[i] != 0ull) atomicAdd(g_patch_acc + i, acc[i]);
+    // arrival ticket: this workgroup's adds are performed device-wide before its ticket is taken
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&g_patch_arrived, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const unsigned poison = atomicExch(&g_patch_poison, 0u);
+    const double from_fix = ldexp(1.0, -(62 - count_bits - e));
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const long long v = (long long)atomicExch(g_patch_acc + i, 0ull);       // read at the coherence point and re-arm
+        dpatch[i] = poison ? __uint_as_float(0x7fc00000u) : (float)((double)v * from_fix);
+    }
+    if (threadIdx.x == 0) { atomicExch(&g_patch_arrived, 0u); atomicExch(&g_patch_max_bits, 0u); }
 }
 
 __global__ void clamp_kernel(float* __restrict__ x, float lo, float hi, int64_t n) {
@@ -224,10 +294,17 @@ void k_patch_overlay(const float* img, const float* patch, const float* mats, co
 void k_patch_overlay_bwd(const float* g, const float* mats, const float* persp, float* dpatch, int B, int S, int ps, int circle,
                          hipStream_t s) {
     ProfScope prof_("patch_overlay_bwd_kernel", 0.0, (double)B * 3 * S * S * 4.0, s);
-    (void)hipMemsetAsync(dpatch, 0, (size_t)3 * ps * ps * sizeof(float), s);
     const int bands = 8;
-    hipLaunchKernelGGL(patch_overlay_bwd_kernel, dim3(B * bands), dim3(256), (size_t)3 * ps * ps * sizeof(float), s, g, mats,
-                       persp, dpatch, S, ps, circle, bands);
+    const size_t lds = (size_t)3 * ps * ps * sizeof(unsigned long long);
+    if (lds > 48 * 1024)       // ps > 45: above the default dynamic-LDS limit (not a stream operation; legal under capture)
+        (void)hipFuncSetAttribute((const void*)patch_overlay_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // contributions of the whole call: pixels x 3 channels are separate entries, so per entry at most B * S * S pixels x 4 affine
+    // taps x (4 perspective taps) x 4 resize taps
+    double cnt = (double)B * S * S * 16.0 * (persp ? 4.0 : 1.0);
+    int count_bits = 1;
+    while (ldexp(1.0, count_bits) < cnt) ++count_bits;
+    hipLaunchKernelGGL(patch_grad_max_kernel, dim3(B * bands), dim3(256), 0, s, g, mats, persp, S, ps, circle, bands);
+    hipLaunchKernelGGL(patch_overlay_bwd_kernel, dim3(B * bands), dim3(256), lds, s, g, mats, persp, dpatch, S, ps, circle, bands, count_bits);
 }
 void k_clamp(float* x, float lo, float hi, int64_t n, hipStream_t s) {
     int64_t blocks = (n + 255) / 256;

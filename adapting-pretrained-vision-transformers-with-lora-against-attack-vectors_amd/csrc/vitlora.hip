@@ -16,7 +16,7 @@
 #include "prof.h"
 
 // This file is compiled twice (common.h): process-wide state and the entry points without a handle exist once, in the fp16 build.
-extern std::vector<vl_model*> g_vl_models;      // live handles of BOTH builds (vl_adam_step finds the model a flat buffer belongs to)
+extern std::vector<VlFlatRecord> g_vl_models;      // live handles of BOTH builds (vl_adam_step finds the model a flat buffer belongs to)
 extern long long g_poison_count;
 #ifndef VL_BF16
 Profiler* g_prof = nullptr;
@@ -41,7 +41,7 @@ void vl_poison_lds(hipStream_t s) {
     hipLaunchKernelGGL(poison_lds_kernel, dim3(2 * cus), dim3(256), 160 * 1024, s, 0xFFFFFFFFu, (unsigned*)nullptr);
     if (hipGetLastError() == hipSuccess) ++g_poison_count;
 }
-std::vector<vl_model*> g_vl_models;
+std::vector<VlFlatRecord> g_vl_models;
 namespace {
 thread_local std::string g_err;
 }
@@ -233,6 +233,8 @@ int check_async(vl_model* m) {
                                    "redo that batch with precision = f32");
         if (code == 3) return fail(VL_ERR_NONFINITE, "an earlier vl_adam_step saw a non-finite parameter gradient (those elements were "
                                    "skipped): drop that step or redo it with precision = f32");
+        if (code == 4) return fail(VL_ERR_NONFINITE, "an earlier FORWARD pass left the fp16 range (the 16-bit residual stream exceeded 65504): "
+                                   "redo that batch with precision = f32 or bf16");
         return fail(VL_ERR_HIP, "device-side error flag %d", code);
     }
     return VL_OK;
@@ -283,6 +285,8 @@ int vl_create(const vl_config* cfg, vl_model** out) {
 #else
     if (cfg->precision != VL_PREC_F16 && cfg->precision != VL_PREC_F32) return fail(VL_ERR_ARG, "unknown precision %d", cfg->precision);
 #endif
+    if (cfg->precision != VL_PREC_F32 && cfg->hidden > 1024)      // k_layernorm_fwd16 / bwd16 hold a row in registers: D <= 1024 (ViT-B / ViT-L); round-4 ADVICE: refuse here, not by abort() at the first forward
+        return fail(VL_ERR_UNSUPPORTED, "hidden %d: the 16-bit path supports hidden <= 1024 (ViT-B/16, ViT-L/16); use precision = f32", cfg->hidden);
     if (cfg->precision == VL_PREC_F32 && cfg->lora_targets && cfg->lora_r % 4)
         return fail(VL_ERR_UNSUPPORTED, "fp32 mode needs lora_r %% 4 == 0");
     int dev = 0;
@@ -375,7 +379,7 @@ int vl_create(const vl_config* cfg, vl_model** out) {
     // at API entry without synchronising)
     if (hipHostMalloc((void**)&m->err_flag, 64, hipHostMallocMapped) != hipSuccess) { vl_destroy(m); return fail(VL_ERR_HIP, "hipHostMalloc failed"); }
     *m->err_flag = 0;
-    g_models.push_back(m);
+    g_models.push_back(VlFlatRecord{m, m->flat, m->flat_n, &m->dirty, &m->err_flag});
     *out = m;
     return VL_OK;
 }
@@ -389,7 +393,7 @@ int vl_destroy(vl_model* m) {
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->err_flag) (void)hipHostFree(m->err_flag);
-    for (size_t i = 0; i < g_models.size(); ++i) if (g_models[i] == m) { g_models.erase(g_models.begin() + i); break; }
+    for (size_t i = 0; i < g_models.size(); ++i) if (g_models[i].model == (void*)m) { g_models.erase(g_models.begin() + i); break; }
     delete m;
     return VL_OK;
 }
@@ -626,6 +630,9 @@ static size_t carve(vl_model* m, int B, int train, char* base) {
     w.dz = (h16*)take((size_t)Mpad * MLP * 2);
     w.u = (h16*)take((size_t)Mpad * kext_max * 2);
     w.xd = train ? (h16*)take((size_t)Mpad * MLP * 2) : nullptr;
+    // per-chunk copies of the LoRA gradient (deterministic weight gradients: lora_grad.hip); the LoRA parameters are the
+    // first cls_w_off elements of the flat buffer
+    w.wg_slab = train && m->cls_w_off > 0 ? (float*)take((size_t)lora_wgrad_chunks((int)((int64_t)B * m->T)) * (size_t)m->cls_w_off * 4) : nullptr;
     return off;
 }
 
@@ -870,7 +877,8 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
     // gradients (sums over images) one common scale is used.  Undone in the patch epilogue / the wgrad scale.
     k_grad_scale(w.dlogits, B, m->C, flat_grad ? 1 : 0, w.gscale, w.inv_gscale, s);
     if (flat_grad) {
-        HIPCHK(hipMemsetAsync(flat_grad, 0, (size_t)m->flat_n * sizeof(float), s));
+        // every element is written: the classifier's here, the LoRA matrices' by k_reduce_chunks at the end (modules without an
+        // adapter have no elements in the flat buffer)
         k_classifier_grad(w.dlogits, w.xf, B, D, m->C, flat_grad + m->cls_w_off, flat_grad + m->cls_b_off, s);
     }
     const bool cls_only = m->cur_cls_only != 0;
@@ -890,10 +898,10 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
         }
         for (const Slot& sl : ln.slots) {
             // dB[n][j] = s * sum_m dy[m][row_off+n] * t[m][ext_off+j]
-            k_lora_wgrad(dy + sl.row_off, ln.out, sl.out, t + sl.ext_off, ln.kext, r, M, sc, flat_grad + sl.b_off, r, 0,
-                         w.inv_gscale, s);
+            k_lora_wgrad(dy + sl.row_off, ln.out, sl.out, t + sl.ext_off, ln.kext, r, M, sc, w.wg_slab + sl.b_off, r, 0,
+                         w.inv_gscale, m->cls_w_off, s);
             // dA[j][k] = s * sum_m u[m][ext_off+j] * x[m][k]   (computed transposed: L = x)
-            k_lora_wgrad(x, ln.in, sl.in, u + sl.ext_off, ln.kext, r, M, sc, flat_grad + sl.a_off, sl.in, 1, w.inv_gscale, s);
+            k_lora_wgrad(x, ln.in, sl.in, u + sl.ext_off, ln.kext, r, M, sc, w.wg_slab + sl.a_off, sl.in, 1, w.inv_gscale, m->cls_w_off, s);
         }
     };
 
@@ -958,6 +966,8 @@ static int backward_impl(vl_model* m, float* grad_x, float* flat_grad, hipStream
         k_layernorm_bwd16(w.dh, w.xs16[2 * l], w.mean[2 * l], w.rstd[2 * l], ly.ln1_g, w.dres_h, M, D,
                           ff ? m->layers[l - 1].lin[LFC2].Bd : nullptr, ff, w.u, s, m->err_flag);
     }
+    if (flat_grad && m->cls_w_off > 0)      // the chunk copies summed in chunk order: bit-reproducible LoRA gradients
+        k_reduce_chunks(w.wg_slab, flat_grad, m->cls_w_off, lora_wgrad_chunks(M), m->cls_w_off, s);
     if (grad_x || pf) {
         // d(pixels): patch rows of d(x0) times Wpe, scattered back to NCHW, chain rule of (x-mean)/std
         GemmArgs g = gemm_args(w.dres_h, D, m->WpeT, D, D, Mppad, m->PK);
@@ -1011,10 +1021,11 @@ static int backward_api(vl_model* m, float* grad_x, float* flat_grad, hipStream_
             (void)hipMemcpyAsync(m->ws.dlogits, main_dlogits + (size_t)(c ? b0 : 0) * m->C, (size_t)m->chain_B[c] * m->C * sizeof(float),
                                  hipMemcpyDeviceToDevice, sc);
             m->cur_B = m->chain_B[c]; m->cur_cls_only = m->chain_cls[c]; m->have_loss = 1;
+            m->cur_M = m->chain_B[c] * m->T;          // Mvalid of this chain's dgrad GEMMs: its own rows (round-4 ADVICE: pad rows of the chain workspace were stored with dead_rows = 0)
             rcs[c] = backward_impl(m, grad_x ? grad_x + (c ? b0 * img : 0) : nullptr, nullptr, sc);
             std::swap(m->ws, m->chain_ws[c]);
         }
-        m->cur_B = batch;
+        m->cur_B = batch; m->cur_M = batch * m->T;
         HIPCHK(hipEventRecord(m->ev_join, m->side_stream));
         HIPCHK(hipStreamWaitEvent(s, m->ev_join, 0));
         if (rcs[0] || rcs[1]) return rcs[0] ? rcs[0] : rcs[1];
@@ -1275,8 +1286,8 @@ int vl_adam_step(float* param, const float* grad, float* m1, float* m2, float lr
                  int64_t n, void* stream) {
     if (!param || !grad || !m1 || !m2 || n <= 0 || t <= 0) return fail(VL_ERR_ARG, "bad argument");
     int* err = nullptr;
-    for (vl_model* mm : g_models)      // optimizer.step() on a model's flat parameters: its operands are stale now
-        if (param < mm->flat + mm->flat_n && param + n > mm->flat) { mm->dirty = 1; err = mm->err_flag; }
+    for (const VlFlatRecord& mm : g_models)      // optimizer.step() on a model's flat parameters: its operands are stale now
+        if (param < mm.flat + mm.flat_n && param + n > mm.flat) { *mm.dirty = 1; err = *mm.err_flag; }
     k_adam(param, grad, m1, m2, lr, b1, b2, eps, t, n, (hipStream_t)stream, err);
     return VL_OK;
 }

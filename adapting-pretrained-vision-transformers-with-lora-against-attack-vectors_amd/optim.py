@@ -121,3 +121,11 @@ class Adam:
         # this step (unlike torch.optim.Adam, which never writes .grad) -- a second step() without a new backward is a no-op
         # instead of re-applying a rescaled gradient
         p.grad = None
+
+    def drop_last_step(self):
+        """The step just taken was dropped by the fused kernel (every element of the reduced gradient non-finite: what
+        train_loras.py injects to skip a step whose fp16 backward left the range): do not count it in Adam's bias correction
+        -- an AMP skip-step never calls optimizer.step(), so torch.optim.Adam's step count does not advance either
+        (round-4 ADVICE).  Identical on every rank: the NaN gradient rode the all-reduce."""
+        if self.t > 0:
+            self.t -= 1

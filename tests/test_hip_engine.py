@@ -316,6 +316,35 @@ def test_lora_train_grads(prec, r):
         assert rel_l2(got, grads[("cls", which)]) < TOL_GRAD[prec]
 
 
+@pytest.mark.parametrize("prec", ["f16", "bf16", "f32"])
+def test_lora_gradients_are_bit_reproducible_and_need_no_zeroed_output(prec):
+    """Two backward passes of the same train step give the same LoRA / classifier gradient BIT FOR BIT (round 5: the weight
+    gradients are summed as per-chunk partial blocks in chunk order, csrc/lora_grad.hip; rounds 1-4 used float atomics and two
+    identical training runs were not bit-reproducible).  224-pixel images x 8 = 1 576 token rows = 4 chunks of 512, so the
+    chunk reduction is exercised; the output buffer is handed over full of NaN to show that every element is written
+    (train_loras.py:310-314 -- the determinism SURVEY section 4 (iv) asks of the data-parallel gradient)."""
+    cfg, w, lora, x, y = make_case(image_size=224, batch=8, r=8, targets=("q", "k", "v", "o", "fc2"))
+    eng = make_engine(cfg, w, lora, precision=prec)
+    xn = O.normalise(x).cuda()
+    outs = []
+    for rep in range(3):
+        eng.forward(xn, normalise=False, train=True)
+        eng.loss_ce(y.cuda())
+        gp = torch.full_like(eng.flat, float("nan"))
+        import ctypes as C
+        rc = eng.lib.vl_backward(eng.h, C.c_void_p(0), C.c_void_p(gp.data_ptr()), eng._stream())
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        assert torch.isfinite(gp).all()
+        outs.append(gp.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    if prec != "bf16":
+        l_ref, lg_ref, grads = O.lora_train_grads(w, cfg, O.normalise(x), y, lora)
+        v = eng.param(0, "q", "A")
+        off = (v.data_ptr() - eng.flat.data_ptr()) // 4
+        assert rel_l2(outs[0][off:off + v.numel()].view(v.shape).cpu(), grads[("A", 0, "q")]) < TOL_GRAD[prec]
+
+
 @pytest.mark.parametrize("prec", PRECS)
 def test_lora_dropout_train_mode_matches_oracle_with_same_masks(prec):
     """lora_dropout > 0 (the reference trains with 0.1, train_loras.py:79): the HIP path's masks are

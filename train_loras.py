@@ -221,6 +221,7 @@ def train_rank(args, D, base_model, sets, rank_r, out_dir, mean, std):
                 engine.check()            # the Adam kernel's own flag (code 3): identical on every rank after the all-reduce
             except V.NonFiniteGradient:
                 skipped += 1
+                optimizer.drop_last_step()      # a dropped step does not advance Adam's bias-correction count
             steps_total += 1
         D.sum_(stats)
         res["train_loss"].append(float(stats[0] / stats[2].clamp_min(1)))
