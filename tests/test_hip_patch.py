@@ -176,10 +176,18 @@ def test_patch_train_steps_with_distortion_match_oracle():
         patch_mod.AdversarialPatchPyTorch(P.LogitsModel(model), distortion_scale_max=1.0, patch_shape=(3, 16, 16))
 
 
+# config 5 names bf16: measured errors of the 24-layer ViT-L/16 + LoRA r = 16 against the fp32 oracle, per 16-bit mode.  fp16 is held
+# to the suite's 16-bit tolerances (north_star allows 1e-2); bf16 is held to its MEASURED error with ~30 % head room and does NOT
+# meet 1e-2 at this depth (include/vitlora.h beside VL_PREC_BF16, DESIGN.md section 0: the bf16 MFMA operands alone exceed it; CPU
+# pricing of every mixed storage variant in profiles/r05_bf16_mixed_mode_cpu.txt) -- which is why patch_attack.py defaults to f16.
+VITL_TOL = {"f16": dict(logits=4e-3, ce=4e-3, gx=6e-3, dp=6e-3), "bf16": dict(logits=2.0e-2, ce=2.0e-2, gx=3.0e-2, dp=3.0e-2)}
+
+
 def test_vit_l16_full_depth_patch_gradient_small_batch():
     """BASELINE config 5's model at full depth: ViT-L/16 (24 layers, hidden 1024, 16 heads, mlp 4096) + LoRA r = 16, one EoT
-    step on 2 images -- CE and d(CE)/d(patch) against the oracle (the patch gradient folds the whole 24-layer input
-    gradient through the warp)."""
+    step on 2 images -- logits, CE, d(CE)/d(pixels) and d(CE)/d(patch) against the fp32 oracle (the patch gradient folds the
+    whole 24-layer input gradient through the warp), in fp16 AND in bf16 (round-4 verdict, missing 1: config 5's own dtype had
+    no oracle comparison at depth); the measured errors are printed (pytest -s) and recorded in profiles/r05_parity_report.txt."""
     P = pkg()
     torch.set_num_threads(16)
     cfg = O.OracleConfig(hidden=1024, layers=24, heads=16, mlp=4096, num_labels=21)
@@ -188,20 +196,28 @@ def test_vit_l16_full_depth_patch_gradient_small_batch():
     g = torch.Generator().manual_seed(33)
     x = torch.rand(2, 3, 224, 224, generator=g)
     y = torch.randint(0, 21, (2,), generator=g)
-    eng = make_engine(cfg, w, lora)
     params = [(0.35, 12.0, 20.0, -31.0), (0.6, -8.0, -14.0, 9.0)]
     patch = torch.rand(3, 32, 32, generator=g)
     mats = _mats(P, params).cuda()
-    patched = eng.patch_apply(x.cuda(), patch.cuda(), mats, 1)
-    logits = eng.forward(patched, normalise=True).cpu()
-    ce = eng.loss_ce(y.cuda()).item()
-    gx, _ = eng.backward(True, False, tuple(x.shape))
-    dp = eng.patch_grad(gx, mats, 32, 1).cpu()
     net = lambda z: O.vit_forward(w, cfg, O.normalise(z), lora)
     ce_ref, dp_ref = PO.patch_loss_and_grad(net, x, y, patch, "circle", params)
-    assert abs(ce - ce_ref.item()) < 4e-3 * ce_ref.item()
-    assert rel_l2(dp, dp_ref) < 6e-3, rel_l2(dp, dp_ref)
-    assert rel_l2(logits, net(PO.overlay(x, patch, "circle", params))) < 4e-3
+    patched_ref = PO.overlay(x, patch, "circle", params)
+    logits_ref = net(patched_ref)
+    _, gx_ref, _ = O.loss_and_input_grad(w, cfg, patched_ref, y, lora)
+    for prec in ("f16", "bf16"):
+        eng = make_engine(cfg, w, lora, precision=prec)
+        patched = eng.patch_apply(x.cuda(), patch.cuda(), mats, 1)
+        logits = eng.forward(patched, normalise=True).cpu()
+        ce = eng.loss_ce(y.cuda()).item()
+        gx, _ = eng.backward(True, False, tuple(x.shape))
+        dp = eng.patch_grad(gx, mats, 32, 1).cpu()
+        err = dict(logits=rel_l2(logits, logits_ref), ce=abs(ce - ce_ref.item()) / ce_ref.item(), gx=rel_l2(gx.cpu(), gx_ref),
+                   dp=rel_l2(dp, dp_ref))
+        print(f"ViT-L/16 24 layers + LoRA r=16, {prec}: " + "  ".join(f"{k} {v:.2e}" for k, v in err.items()))
+        for k, v in err.items():
+            assert v < VITL_TOL[prec][k], (prec, k, v)
+        del eng
+        torch.cuda.empty_cache()
 
 
 def test_patch_attack_cli_synthetic(tmp_path):
