@@ -1002,10 +1002,12 @@ struct SLin {
     float *W = nullptr, *b = nullptr;
     std::vector<SLora> slots;
     // 16-bit path: operands zero-padded to multiples of 128 in both directions (the h16 GEMM kernels' tile sizes)
-    int inP = 0, outP = 0, kext = 0;
-    h16 *W16 = nullptr, *WT16 = nullptr;      // [outP][inP], [inP][outP]
-    float* b16 = nullptr;                     // [outP] fp32, zero padded
-    h16 *Ad = nullptr, *Bu = nullptr, *Bd = nullptr, *Au = nullptr;   // [64][inP], [outP][64] (scaled), [64][outP], [inP][64] (scaled)
+    int inP = 0, outP = 0, kext = 0;          // widths in the K role (multiples of 128)
+    int inN = 0, outN = 0;                    // widths in the N role (round 5): a multiple of 256 where that puts the GEMM on the 256-wide
+                                              // tile kernels (C = 384: N = 384 -> 512, 1152 -> 1280; the extra weight rows are zero)
+    h16 *W16 = nullptr, *WT16 = nullptr;      // [outN][inP], [inN][outP]
+    float* b16 = nullptr;                     // [outN] fp32, zero padded
+    h16 *Ad = nullptr, *Bu = nullptr, *Bd = nullptr, *Au = nullptr;   // [64][inP], [outN][64] (scaled), [64][outP], [inN][64] (scaled)
 };
 struct SBlock {
     SLin qkv, o, fc1, fc2;
@@ -1023,6 +1025,7 @@ struct SStage {
     float *mg = nullptr, *mmean = nullptr, *mrstd = nullptr;    // saved
     // 16-bit path: per-stage scratch (strides are the stage's own padded widths: pad columns stay zero for ever)
     int CP = 0, C3P = 0, C4P = 0;             // GEMM dims: C, 3C, 4C rounded up to the 128-wide tiles (weights are zero padded)
+    int LD = 0;                               // row stride of the GEMM RESULTS of width C (delta16, dh16, dctx16): LC, or the N-role width of C
     int LC = 0, L3 = 0, L4 = 0;               // row strides of the h16 activations: the padded dims, or C, 3C, 4C themselves
                                               // (stage 1: 96 / 288 / 384 -- a quarter fewer bytes on every tensor of the HBM-bound
                                               // stage; the GEMM then reads its last K columns from the NEXT row, times zero weights,
@@ -1107,6 +1110,10 @@ void lin_dgrad(vl_swin* m, const SLin& ln, const float* dy, int M, float* dx, hi
 
 // ---- 16-bit path: packed operands, block forward / backward --------------------------------------------------------------
 inline int padc(int c) { return (int)round_up(c, 128); }
+// N-role width of a padded dimension `n` in a stage of width C: stages whose token count puts their GEMMs on the 256-wide tile
+// kernels (C >= 384: M <= 50 176 rows at batch 256) round N up to a multiple of 256 -- 128-column remainders (384, 1152) otherwise
+// send the whole product to the 128 x 128 kernel at half the rate (round 5: 2.5 ms of a 20.6 ms step)
+inline int npad(int C, int n) { return (C >= 384 && n % 256) ? (int)round_up(n, 256) : n; }
 
 GemmArgs ga(const h16* A, int lda, const h16* W, int ldw, int K, int M, int N) {
     GemmArgs g;
@@ -1145,8 +1152,8 @@ void swin16_commit(vl_swin* m, hipStream_t s) {
 // y = x W^T + b (+ LoRA as one extra K tile), epilogue `epi`; x [Mp][inP] h16
 void lin16_fwd(vl_swin* m, SStage& st, const SLin& ln, const h16* x, int ldx, int Mp, int M, GemmArgs g, int epi, hipStream_t s) {
     g.A1 = x; g.lda1 = ldx; g.W1 = ln.W16; g.ldw1 = ln.inP; g.K1 = ln.inP;
-    g.M = Mp; g.Mvalid = M; g.N = ln.outP; g.bias = ln.b16;
-    g.n_store = g.ldc < ln.outP ? ln.out : 0;                      // unpadded result rows (ldc = out)
+    g.M = Mp; g.Mvalid = M; g.N = ln.outN; g.bias = ln.b16;
+    g.n_store = g.ldc < ln.outN ? ln.out : 0;                      // unpadded result rows (ldc = out)
     if (ln.kext) {
         g.W2 = ln.Bu; g.ldw2 = 64; g.K2 = 64;
         g.k2_algo = m->r; g.k2_used = m->r * (int)ln.slots.size();
@@ -1164,8 +1171,8 @@ void lin16_fwd(vl_swin* m, SStage& st, const SLin& ln, const h16* x, int ldx, in
 // dx = dy W (+ LoRA), dy [Mp][outP] h16
 void lin16_dgrad(vl_swin* m, SStage& st, const SLin& ln, const h16* dy, int ldy, int Mp, int M, GemmArgs g, int epi, hipStream_t s) {
     g.A1 = dy; g.lda1 = ldy; g.W1 = ln.WT16; g.ldw1 = ln.outP; g.K1 = ln.outP;
-    g.M = Mp; g.Mvalid = M; g.N = ln.inP; g.bias = nullptr;
-    g.n_store = g.ldc < ln.inP ? ln.in : 0;
+    g.M = Mp; g.Mvalid = M; g.N = ln.inN; g.bias = nullptr;
+    g.n_store = g.ldc < ln.inN ? ln.in : 0;
     if (ln.kext) {
         g.W2 = ln.Au; g.ldw2 = 64; g.K2 = 64;
         g.k2_algo = m->r * (int)ln.slots.size(); g.k2_used = g.k2_algo;
@@ -1189,7 +1196,7 @@ void swin16_block_fwd(vl_swin* m, SStage& st, SBlock& bk, const h16* x_prev16, b
     const int Cs = st.C, Hs = st.H, M = B * Hs * Hs, Mp = (int)round_up(M, 128);
     const int nW = (Hs / WS) * (Hs / WS);
     GemmArgs g;
-    if (add_delta) sw_ln_fwd16<false>(x_prev16, Cs, st.delta16, st.LC, bk.xa16, Cs, st.h16b, st.LC, bk.mean1, bk.rstd1, bk.ln1_g, bk.ln1_b, M, Cs, m->cfg.ln_eps, m->err_flag, s);
+    if (add_delta) sw_ln_fwd16<false>(x_prev16, Cs, st.delta16, st.LD, bk.xa16, Cs, st.h16b, st.LC, bk.mean1, bk.rstd1, bk.ln1_g, bk.ln1_b, M, Cs, m->cfg.ln_eps, m->err_flag, s);
     else sw_ln_fwd16<false>(bk.xa16, Cs, nullptr, 0, nullptr, 0, st.h16b, st.LC, bk.mean1, bk.rstd1, bk.ln1_g, bk.ln1_b, M, Cs, m->cfg.ln_eps, m->err_flag, s);
     memset(&g, 0, sizeof g); g.C = bk.qkv16; g.ldc = st.L3;
     lin16_fwd(m, st, bk.qkv, st.h16b, st.LC, Mp, M, g, EPI_STORE_H16, s);
@@ -1197,13 +1204,13 @@ void swin16_block_fwd(vl_swin* m, SStage& st, SBlock& bk, const h16* x_prev16, b
     if (g_poison_lds) vl_poison_lds(s);      // test hook (prof.h): the window kernels keep K / V / Q / dO of a window in LDS
     hipLaunchKernelGGL(win16_fwd_kernel, dim3(win16_grid(witems, st.heads, 8)), dim3(64), 0, s,
                        bk.qkv16, st.L3, bk.table, st.ctx16, st.LC, bk.lse, B, Hs, Hs, Cs, st.heads, shift, witems);
-    memset(&g, 0, sizeof g); g.C = st.delta16; g.ldc = st.LC;
+    memset(&g, 0, sizeof g); g.C = st.delta16; g.ldc = st.LD;
     lin16_fwd(m, st, bk.o, st.ctx16, st.LC, Mp, M, g, EPI_STORE_H16, s);
     // LayerNorm 2 (+ residual add of the attention output: xa16 + delta -> xb16)
-    sw_ln_fwd16<false>(bk.xa16, Cs, st.delta16, st.LC, bk.xb16, Cs, st.h16b, st.LC, bk.mean2, bk.rstd2, bk.ln2_g, bk.ln2_b, M, Cs, m->cfg.ln_eps, m->err_flag, s);
+    sw_ln_fwd16<false>(bk.xa16, Cs, st.delta16, st.LD, bk.xb16, Cs, st.h16b, st.LC, bk.mean2, bk.rstd2, bk.ln2_g, bk.ln2_b, M, Cs, m->cfg.ln_eps, m->err_flag, s);
     memset(&g, 0, sizeof g); g.C = st.a16; g.ldc = st.L4; g.C2 = bk.z16; g.ldc2 = st.L4;
     lin16_fwd(m, st, bk.fc1, st.h16b, st.LC, Mp, M, g, EPI_GELU, s);
-    memset(&g, 0, sizeof g); g.C = st.delta16; g.ldc = st.LC;
+    memset(&g, 0, sizeof g); g.C = st.delta16; g.ldc = st.LD;
     lin16_fwd(m, st, bk.fc2, st.a16, st.L4, Mp, M, g, EPI_STORE_H16, s);
 }
 
@@ -1215,18 +1222,18 @@ void swin16_block_bwd(vl_swin* m, SStage& st, SBlock& bk, int B, int shift, hipS
     GemmArgs g;
     memset(&g, 0, sizeof g); g.C = st.dz16; g.ldc = st.L4; g.R = bk.z16; g.ldr = st.L4;
     lin16_dgrad(m, st, bk.fc2, st.gh16, st.LC, Mp, M, g, EPI_GELU_BWD, s);                         // d(z) = (d(out) Wfc2) * gelu'(z)
-    memset(&g, 0, sizeof g); g.C = st.dh16; g.ldc = st.LC;
+    memset(&g, 0, sizeof g); g.C = st.dh16; g.ldc = st.LD;
     lin16_dgrad(m, st, bk.fc1, st.dz16, st.L4, Mp, M, g, EPI_STORE_H16, s);
-    sw_ln_bwd16<false, false>(st.dh16, st.LC, bk.xb16, Cs, bk.mean2, bk.rstd2, bk.ln2_g, st.gh16, st.gh16, st.LC, M, Cs, m->err_flag, s);
-    memset(&g, 0, sizeof g); g.C = st.dctx16; g.ldc = st.LC;
+    sw_ln_bwd16<false, false>(st.dh16, st.LD, bk.xb16, Cs, bk.mean2, bk.rstd2, bk.ln2_g, st.gh16, st.gh16, st.LC, M, Cs, m->err_flag, s);
+    memset(&g, 0, sizeof g); g.C = st.dctx16; g.ldc = st.LD;
     lin16_dgrad(m, st, bk.o, st.gh16, st.LC, Mp, M, g, EPI_STORE_H16, s);
     const int64_t witems = (int64_t)B * nW * st.heads;
     if (g_poison_lds) vl_poison_lds(s);      // test hook (prof.h): the window kernels keep K / V / Q / dO of a window in LDS
     hipLaunchKernelGGL(win16_bwd_kernel, dim3(win16_grid(witems, st.heads, 4)), dim3(64), 0, s,
-                       bk.qkv16, st.L3, bk.table, st.dctx16, st.LC, bk.lse, st.dqkv16, B, Hs, Hs, Cs, st.heads, shift, witems);
-    memset(&g, 0, sizeof g); g.C = st.dh16; g.ldc = st.LC;
+                       bk.qkv16, st.L3, bk.table, st.dctx16, st.LD, bk.lse, st.dqkv16, B, Hs, Hs, Cs, st.heads, shift, witems);
+    memset(&g, 0, sizeof g); g.C = st.dh16; g.ldc = st.LD;
     lin16_dgrad(m, st, bk.qkv, st.dqkv16, st.L3, Mp, M, g, EPI_STORE_H16, s);
-    sw_ln_bwd16<false, false>(st.dh16, st.LC, bk.xa16, Cs, bk.mean1, bk.rstd1, bk.ln1_g, st.gh16, st.gh16, st.LC, M, Cs, m->err_flag, s);
+    sw_ln_bwd16<false, false>(st.dh16, st.LD, bk.xa16, Cs, bk.mean1, bk.rstd1, bk.ln1_g, st.gh16, st.gh16, st.LC, M, Cs, m->err_flag, s);
 }
 
 int parse2(const char* name, const char* pfx, int* a, const char** rest) {
@@ -1292,7 +1299,8 @@ int vl_swin_create(const vl_swin_config* cfg, vl_swin** out) {
                 A_(ln->W, (size_t)ln->out * ln->in); A_(ln->b, ln->out);
                 if (m->f16) {
                     ln->inP = padc(ln->in); ln->outP = padc(ln->out);
-                    A_(ln->W16, (size_t)ln->outP * ln->inP); A_(ln->WT16, (size_t)ln->inP * ln->outP); A_(ln->b16, ln->outP);
+                    ln->inN = npad(Cs, ln->inP); ln->outN = npad(Cs, ln->outP);
+                    A_(ln->W16, (size_t)ln->outN * ln->inP); A_(ln->WT16, (size_t)ln->inN * ln->outP); A_(ln->b16, ln->outN);
                 }
             }
             A_(bk.ln1_g, Cs); A_(bk.ln1_b, Cs); A_(bk.ln2_g, Cs); A_(bk.ln2_b, Cs);
@@ -1311,8 +1319,8 @@ int vl_swin_create(const vl_swin_config* cfg, vl_swin** out) {
                     for (SLin* ln : {&bk.qkv, &bk.o, &bk.fc1, &bk.fc2}) {
                         if (ln->slots.empty()) continue;
                         ln->kext = 64;
-                        A_(ln->Ad, (size_t)64 * ln->inP); A_(ln->Bu, (size_t)ln->outP * 64);
-                        A_(ln->Bd, (size_t)64 * ln->outP); A_(ln->Au, (size_t)ln->inP * 64);
+                        A_(ln->Ad, (size_t)64 * ln->inP); A_(ln->Bu, (size_t)ln->outN * 64);
+                        A_(ln->Bd, (size_t)64 * ln->outP); A_(ln->Au, (size_t)ln->inN * 64);
                     }
             }
         }
@@ -1458,17 +1466,19 @@ static size_t swin_carve(vl_swin* m, int B, char* base) {
             const int64_t Rp = round_up((int64_t)B * st.H * st.H, 128);
             st.CP = padc(st.C); st.C3P = padc(3 * st.C); st.C4P = padc(4 * st.C);
             const bool unpad = ((m->unpad_stages >> i) & 1) && st.C % 32 == 0;
-            st.LC = unpad ? st.C : st.CP; st.L3 = unpad ? 3 * st.C : st.C3P; st.L4 = unpad ? 4 * st.C : st.C4P;
+            st.LC = unpad ? st.C : st.CP; st.L3 = unpad ? 3 * st.C : npad(st.C, st.C3P); st.L4 = unpad ? 4 * st.C : st.C4P;
+            st.LD = unpad ? st.C : npad(st.C, st.CP);
             // (+ 512 B: a GEMM whose A rows are narrower than its K reads that far past the last row)
             auto th = [&](size_t n) { return (h16*)take(n * 2 + 512); };
             for (SBlock& bk : st.blocks) {
-                bk.qkv16 = th((size_t)Rp * st.C3P); bk.z16 = th((size_t)Rp * st.C4P);
+                bk.qkv16 = th((size_t)Rp * npad(st.C, st.C3P)); bk.z16 = th((size_t)Rp * st.C4P);
                 bk.xa16 = th((size_t)Rp * st.C); bk.xb16 = th((size_t)Rp * st.C);
             }
-            st.h16b = th((size_t)Rp * st.CP); st.a16 = th((size_t)Rp * st.C4P); st.delta16 = th((size_t)Rp * st.CP);
+            const size_t CD = (size_t)npad(st.C, st.CP);
+            st.h16b = th((size_t)Rp * st.CP); st.a16 = th((size_t)Rp * st.C4P); st.delta16 = th((size_t)Rp * CD);
             st.ctx16 = th((size_t)Rp * st.CP); st.t16 = th((size_t)Rp * 64); st.u16 = th((size_t)Rp * 64);
-            st.dz16 = th((size_t)Rp * st.C4P); st.dqkv16 = th((size_t)Rp * st.C3P); st.dh16 = th((size_t)Rp * st.CP);
-            st.dctx16 = th((size_t)Rp * st.CP); st.gh16 = th((size_t)Rp * st.CP);
+            st.dz16 = th((size_t)Rp * st.C4P); st.dqkv16 = th((size_t)Rp * npad(st.C, st.C3P)); st.dh16 = th((size_t)Rp * CD);
+            st.dctx16 = th((size_t)Rp * CD); st.gh16 = th((size_t)Rp * st.CP);
             if (i < 3) { const int64_t Rq = round_up(Rp / 4, 128); st.mg16 = th((size_t)Rq * 4 * st.C); st.g16 = th((size_t)Rq * 2 * st.C); }
         }
         if (i < 3) { if (!m->f16) st.mg = take((size_t)R / 4 * 4 * st.C * 4 + 1024); st.mmean = take((size_t)R); st.mrstd = take((size_t)R); }
@@ -1559,7 +1569,7 @@ static int swin_forward(vl_swin* m, const float* x, int B, int normalise, hipStr
             const SBlock& last = st.blocks[st.depth - 1];
             if (i == 3) {
                 // stage output x' = round16(xb + delta) -> xlast16, and the final LayerNorm over every token in the same pass
-                sw_ln_fwd16<false>(last.xb16, Cs, st.delta16, st.LC, m->xlast16, Cs, m->hfin16, Cs, m->fmean, m->frstd, m->fg, m->fb, M, Cs,
+                sw_ln_fwd16<false>(last.xb16, Cs, st.delta16, st.LD, m->xlast16, Cs, m->hfin16, Cs, m->fmean, m->frstd, m->fg, m->fb, M, Cs,
                                    m->cfg.ln_eps, m->err_flag, s);
                 break;
             }
@@ -1569,7 +1579,7 @@ static int swin_forward(vl_swin* m, const float* x, int B, int normalise, hipStr
             merge_dispatch(Cs, [&](auto nv, auto gl) {
                 constexpr int NV = decltype(nv)::value, GL = decltype(gl)::value;
                 hipLaunchKernelGGL((merge_ln_fwd16_kernel<NV, GL>), dim3((M / 4 + 4 * (64 / GL) - 1) / (4 * (64 / GL))), dim3(256), 0, s,
-                                   last.xb16, st.delta16, st.LC, st.mg16, st.mmean, st.mrstd, st.mg_g, st.mg_b, B, Hs, Hs, Cs, m->cfg.ln_eps);
+                                   last.xb16, st.delta16, st.LD, st.mg16, st.mmean, st.mrstd, st.mg_g, st.mg_b, B, Hs, Hs, Cs, m->cfg.ln_eps);
             });
             GemmArgs g16a = ga(st.mg16, 4 * Cs, st.Wred16, 4 * Cs, 4 * Cs, Mq, N2);
             g16a.Mvalid = M / 4; g16a.C = m->stages[i + 1].blocks[0].xa16; g16a.ldc = 2 * Cs; g16a.n_store = N2 > 2 * Cs ? 2 * Cs : 0;
@@ -1653,7 +1663,7 @@ static int swin_backward(vl_swin* m, float* grad_x, hipStream_t s) {
                 merge_dispatch(Cs, [&](auto nv, auto gl) {
                     constexpr int NV = decltype(nv)::value, GL = decltype(gl)::value;
                     hipLaunchKernelGGL((merge_ln_bwd16_kernel<NV, GL>), dim3((M / 4 + 4 * (64 / GL) - 1) / (4 * (64 / GL))), dim3(256), 0, s,
-                                       st.mg16, st.blocks[st.depth - 1].xb16, st.delta16, st.LC, st.mmean, st.mrstd, st.mg_g, st.gh16,
+                                       st.mg16, st.blocks[st.depth - 1].xb16, st.delta16, st.LD, st.mmean, st.mrstd, st.mg_g, st.gh16,
                                        st.LC, B, Hs, Hs, Cs, m->err_flag);
                 });
             }
