@@ -125,9 +125,15 @@ int vl_merge_weight(vl_model* m, int layer, uint32_t target, const float* W_in, 
 int vl_set_normalization(vl_model* m, const float mean[3], const float std[3]);
 
 /* Workspace: vl_plan returns the bytes needed for batches up to max_batch;
- * train != 0 additionally keeps what the LoRA weight-gradient needs.  The bytes handed to vl_set_workspace are the ONLY
- * scratch memory the library touches (guard-band tested) and belong to it until the next vl_set_workspace / vl_destroy;
- * results do not depend on what they held before (tested with 0x00 against 0xFF fills). */
+ * train != 0 additionally keeps what the LoRA weight-gradient needs (per-layer activations, and the per-chunk copies of the LoRA
+ * gradient that make it bit-reproducible: at most 32 x the LoRA parameters x 4 B, 123 MB at r = 8).  The bytes handed to
+ * vl_set_workspace are the ONLY scratch memory the library touches (guard-band tested) and belong to it until the next
+ * vl_set_workspace / vl_destroy; results do not depend on what they held before (tested with 0x00 against 0xFF fills).
+ * What the bytes contain on the 16-bit path: the main activation workspace for max_batch images PLUS two half-batch eval
+ * workspaces of ceil(min(max_batch, 191) / 2) images each for the two-chain forms of vl_pgd_attack / vl_forward(train = 0)
+ * ("pgd_chains", "api_chains" below) -- for every plan, train-mode ones included (config 3's step attacks, then trains, through one
+ * handle).  At max_batch = 256 that is about +75 % (ViT-B/16: 12 GB + 9 GB; the chains serve calls with 2 .. 191 images of that
+ * plan); vl_debug_set_option(m, "pgd_chains", 1) BEFORE vl_plan leaves them out (round-4 ADVICE). */
 int vl_plan(vl_model* m, int max_batch, int train, size_t* bytes);
 int vl_set_workspace(vl_model* m, void* ws, size_t bytes);
 
@@ -255,8 +261,11 @@ int vl_swin_param_flat(vl_swin* m, float** ptr, int64_t* numel);
 int vl_swin_param_tensor(vl_swin* m, int stage, int block, uint32_t target, int which, float** ptr, int64_t* numel);
 int vl_swin_set_normalization(vl_swin* m, const float mean[3], const float std[3]);
 int vl_swin_plan(vl_swin* m, int max_batch, size_t* bytes);
-/* as vl_set_workspace; additionally ZEROES the planned bytes (synchronously): the channel-padding columns of the 16-bit
- * activations (96 -> 128 ...) are never written afterwards and meet zero weight columns.  The caller must not write there. */
+/* as vl_set_workspace (the planned bytes are zeroed once, synchronously).  Since round 5 the results do NOT depend on what the
+ * bytes hold between calls (round 4 required them to stay zero where the channel-padding columns were): the 16-bit activations of
+ * stages 1-2 are dense (no pad columns), pad columns that remain are written by the kernel that owns the row, and the K-tail heads
+ * a GEMM reads past the last valid row are zeroed at the start of every forward (csrc/swin.hip: zero_tails_kernel); tested by
+ * filling every planned byte with 0xFF between two runs (tests/test_hip_swin.py). */
 int vl_swin_set_workspace(vl_swin* m, void* ws, size_t bytes);
 int vl_swin_forward(vl_swin* m, const float* x, int batch, int normalise, float* logits_out, void* stream);
 int vl_swin_loss_ce(vl_swin* m, const int64_t* labels, float* loss_out, void* stream);
