@@ -1060,6 +1060,7 @@ struct vl_swin {
     int f16 = 0;             // cfg.reserved[0] == 1: 16-bit operand path for the blocks (embedding, merging and head stay fp32)
     int dirty = 1;           // packed h16 operands are stale (weights / adapters written since the last commit)
     int fuse_merge = 1;      // VITLORA_SWIN_FUSE_MERGE=0: separate materialise / gather / LayerNorm / pack passes around the merges
+    int pp_down = 0;         // VITLORA_SWIN_PP_DOWN=1: stages 3-4 compute the o / fc2 LoRA down projections inside the ping-pong GEMM instead of as separate skinny GEMMs (round 5: built, bit-compatible, time-neutral -- 18.38 / 18.47 vs 18.42 / 18.28 ms per step, alternating on one box -- so the simpler form stays)
     int unpad_stages = 3;    // bit i: stage i keeps its h16 activations at their true width (VITLORA_SWIN_UNPAD; default since round 5: stages 1 and 2, C = 96 / 192 -- every h16 activation is then dense, there are no pad columns at all; stage 2 alone is time-neutral)
 };
 
@@ -1158,7 +1159,10 @@ void lin16_fwd(vl_swin* m, SStage& st, const SLin& ln, const h16* x, int ldx, in
         g.W2 = ln.Bu; g.ldw2 = 64; g.K2 = 64;
         g.k2_algo = m->r; g.k2_used = m->r * (int)ln.slots.size();
         g.down_W = ln.Ad; g.down_ldw = ln.inP; g.down_groups = 1;
-        if (!gemm_stream_fuses_down(g, epi)) {          // t = x Ad^T as its own skinny GEMM, read back as the LoRA K tile's A operand
+        // the down projection rides inside the GEMM where a kernel can carry it: the streaming kernel (stages 1-2) or, for ONE
+        // adapted module of r <= 16 (o, fc2), the ping-pong kernel's helper group (stages 3-4, round 5)
+        const bool pp_down = m->pp_down && ln.slots.size() == 1 && m->r <= 16 && g.ldc >= ln.outN && gemm_pp_fuses_down(g, epi);
+        if (!gemm_stream_fuses_down(g, epi) && !pp_down) {          // t = x Ad^T as its own skinny GEMM, read back as the LoRA K tile's A operand
             g.down_W = nullptr; g.down_ldw = 0; g.down_groups = 0;
             GemmArgs d = ga(x, ldx, ln.Ad, ln.inP, ln.inP, Mp, 64);
             d.Mvalid = M; d.C = st.t16; d.ldc = 64; d.n_algo = m->r * (int)ln.slots.size();
@@ -1177,7 +1181,8 @@ void lin16_dgrad(vl_swin* m, SStage& st, const SLin& ln, const h16* dy, int ldy,
         g.W2 = ln.Au; g.ldw2 = 64; g.K2 = 64;
         g.k2_algo = m->r * (int)ln.slots.size(); g.k2_used = g.k2_algo;
         g.down_W = ln.Bd; g.down_ldw = ln.outP; g.down_groups = 1;
-        if (!gemm_stream_fuses_down(g, epi)) {
+        const bool pp_down = m->pp_down && ln.slots.size() == 1 && m->r <= 16 && g.ldc >= ln.inN && gemm_pp_fuses_down(g, epi);
+        if (!gemm_stream_fuses_down(g, epi) && !pp_down) {
             g.down_W = nullptr; g.down_ldw = 0; g.down_groups = 0;
             GemmArgs d = ga(dy, ldy, ln.Bd, ln.outP, ln.outP, Mp, 64);
             d.Mvalid = M; d.C = st.u16; d.ldc = 64; d.n_algo = m->r;
@@ -1275,6 +1280,7 @@ int vl_swin_create(const vl_swin_config* cfg, vl_swin** out) {
     m->cfg = *cfg;
     m->f16 = cfg->reserved[0] == 1;
     if (const char* up = getenv("VITLORA_SWIN_UNPAD")) m->unpad_stages = atoi(up);
+    if (const char* pd = getenv("VITLORA_SWIN_PP_DOWN")) m->pp_down = atoi(pd);
     if (const char* fm = getenv("VITLORA_SWIN_FUSE_MERGE")) m->fuse_merge = fm[0] != '0';
     m->S = cfg->image_size; m->P = cfg->patch_size; m->G0 = m->S / m->P; m->E = cfg->embed_dim; m->C = cfg->num_labels;
     m->r = cfg->lora_targets ? cfg->lora_r : 0;
