@@ -8,7 +8,7 @@ OUT=../libvitlora_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 mkdir -p build
 python3 gen_dispatch.py > /dev/null
-HDRS="common.h kernels.h gemm.h prof.h model.h f32_kernels.h gemm_epi.h api_rename.h ../../include/vitlora.h"
+HDRS="common.h kernels.h gemm.h prof.h model.h f32_kernels.h gemm_epi.h api_rename.h mlp_fused.h ../../include/vitlora.h"
 stale() {   # stale <object> <source>
   [ ! -f "$1" ] && return 0
   [ "$2" -nt "$1" ] && return 0
@@ -16,7 +16,7 @@ stale() {   # stale <object> <source>
   return 1
 }
 BOTH="gemm gemm256 gemm_pp gemm_stream elementwise attention32 cls_path lora_grad vitlora"
-ONCE="f32_kernels patch swin vitlora_f32"
+ONCE="f32_kernels patch swin vitlora_f32 mlp_fused"
 pids=()
 njobs=0
 run() { "$@" & pids+=($!); njobs=$((njobs + 1)); if [ $njobs -ge 8 ]; then wait -n || exit 1; njobs=$((njobs - 1)); fi; }

@@ -20,6 +20,7 @@
 #include "f32_kernels.h"
 #include "kernels.h"
 #include "model.h"
+#include "mlp_fused.h"
 #include "prof.h"
 
 namespace VLNS {      // vl_f16 / vl_bf16: the 16-bit path is compiled once per operand type (common.h)
@@ -1060,6 +1061,11 @@ struct vl_swin {
     int f16 = 0;             // cfg.reserved[0] == 1: 16-bit operand path for the blocks (embedding, merging and head stay fp32)
     int dirty = 1;           // packed h16 operands are stale (weights / adapters written since the last commit)
     int fuse_merge = 1;      // VITLORA_SWIN_FUSE_MERGE=0: separate materialise / gather / LayerNorm / pack passes around the merges
+    int mlp_fused = 0;       // VITLORA_SWIN_MLP_FUSED=1: stage 1's MLP (fc1 -> GELU -> fc2, and its backward) in ONE kernel with the hidden activation in
+                             // LDS (csrc/mlp_fused.hip).  Built, tested and measured in round 5 and NOT the default: it removes 2.0 GB of HBM traffic per
+                             // block and is SLOWER (660 + 533 us against 491 + 462 us for the two-launch forms at batch 256): these products are bound
+                             // by the erf-GELU VALU work (308 M elements x ~25 instructions = 0.21 ms per launch) and by per-step synchronisation, not by
+                             // their bytes -- profiles/r05_swin_mlp_fused.txt
     int pp_down = 0;         // VITLORA_SWIN_PP_DOWN=1: stages 3-4 compute the o / fc2 LoRA down projections inside the ping-pong GEMM instead of as separate skinny GEMMs (round 5: built, bit-compatible, time-neutral -- 18.38 / 18.47 vs 18.42 / 18.28 ms per step, alternating on one box -- so the simpler form stays)
     int unpad_stages = 3;    // bit i: stage i keeps its h16 activations at their true width (VITLORA_SWIN_UNPAD; default since round 5: stages 1 and 2, C = 96 / 192 -- every h16 activation is then dense, there are no pad columns at all; stage 2 alone is time-neutral)
 };
@@ -1193,6 +1199,30 @@ void lin16_dgrad(vl_swin* m, SStage& st, const SLin& ln, const h16* dy, int ldy,
     launch_gemm(g, epi, 128, s);
 }
 
+// Arguments of the fused MLP kernel (csrc/mlp_fused.hip) for this block, forward or backward; false when the block's shapes or
+// adapters are outside what it covers (then the two GEMM launches run): C <= 128 -- Swin-T stage 1 --, at most fc2 adapted
+// (one module, r <= 16), unpadded 16-bit activations.
+bool mlp_args(vl_swin* m, SStage& st, SBlock& bk, int Mp, int M, bool backward, MlpArgs* out) {
+    if (!m->mlp_fused || bk.fc1.kext || bk.fc2.slots.size() > 1 || (bk.fc2.kext && m->r > 16)) return false;
+    if (bk.fc2.outN != 128 || bk.fc1.inN != 128 || st.LD != st.C || st.L4 != 4 * st.C) return false;
+    MlpArgs a;
+    memset(&a, 0, sizeof a);
+    a.M = Mp; a.Mvalid = M; a.HID = bk.fc1.outN; a.S = bk.z16; a.lds_ = st.L4; a.n_store = st.C; a.K1_algo = st.C;
+    a.lora = bk.fc2.kext ? 1 : 0; a.r_algo = m->r;
+    if (!backward) {
+        a.X = st.h16b; a.ldx = st.LC; a.K1 = bk.fc1.inP; a.Wa = bk.fc1.W16; a.ldwa = bk.fc1.inP; a.bias1 = bk.fc1.b16;
+        a.Wb = bk.fc2.W16; a.ldwb = bk.fc2.inP; a.bias2 = bk.fc2.b16; a.Y = st.delta16; a.ldy = st.LD;
+        a.Ldown = bk.fc2.Ad; a.ldd = bk.fc2.inP; a.Lup = bk.fc2.Bu;
+    } else {
+        a.X = st.gh16; a.ldx = st.LC; a.K1 = bk.fc2.outP; a.Wa = bk.fc2.WT16; a.ldwa = bk.fc2.outP;
+        a.Wb = bk.fc1.WT16; a.ldwb = bk.fc1.outP; a.Y = st.dh16; a.ldy = st.LD;
+        a.Ldown = bk.fc2.Bd; a.ldd = bk.fc2.outP; a.Lup = bk.fc2.Au;
+    }
+    if (bk.fc1.outN != bk.fc2.inN || bk.fc1.outP != bk.fc1.outN || !mlp_fused_supports(a)) return false;
+    *out = a;
+    return true;
+}
+
 // One Swin block, forward, on the 16-bit residual stream (round 5).  x_prev16: the stream entering the PREVIOUS block's MLP
 // (its xb16) when `add_delta` -- st.delta16 then still holds that block's fc2 output and LayerNorm 1 adds the two on its way
 // (x' = round16(x + delta) -> bk.xa16); otherwise bk.xa16 already is this block's input (first block of a stage).  Leaves the
@@ -1213,6 +1243,11 @@ void swin16_block_fwd(vl_swin* m, SStage& st, SBlock& bk, const h16* x_prev16, b
     lin16_fwd(m, st, bk.o, st.ctx16, st.LC, Mp, M, g, EPI_STORE_H16, s);
     // LayerNorm 2 (+ residual add of the attention output: xa16 + delta -> xb16)
     sw_ln_fwd16<false>(bk.xa16, Cs, st.delta16, st.LD, bk.xb16, Cs, st.h16b, st.LC, bk.mean2, bk.rstd2, bk.ln2_g, bk.ln2_b, M, Cs, m->cfg.ln_eps, m->err_flag, s);
+    MlpArgs ma;
+    if (mlp_args(m, st, bk, Mp, M, false, &ma)) {       // narrow stage: fc1 -> GELU -> fc2 in ONE kernel, the hidden activation stays in LDS
+        launch_mlp_fused(ma, 0, s);
+        return;
+    }
     memset(&g, 0, sizeof g); g.C = st.a16; g.ldc = st.L4; g.C2 = bk.z16; g.ldc2 = st.L4;
     lin16_fwd(m, st, bk.fc1, st.h16b, st.LC, Mp, M, g, EPI_GELU, s);
     memset(&g, 0, sizeof g); g.C = st.delta16; g.ldc = st.LD;
@@ -1225,10 +1260,14 @@ void swin16_block_bwd(vl_swin* m, SStage& st, SBlock& bk, int B, int shift, hipS
     const int Cs = st.C, Hs = st.H, M = B * Hs * Hs, Mp = (int)round_up(M, 128);
     const int nW = (Hs / WS) * (Hs / WS);
     GemmArgs g;
+    MlpArgs ma;
+    if (mlp_args(m, st, bk, Mp, M, true, &ma)) launch_mlp_fused(ma, 1, s);       // fc2 dgrad -> * gelu'(z) -> fc1 dgrad in one kernel
+    else {
     memset(&g, 0, sizeof g); g.C = st.dz16; g.ldc = st.L4; g.R = bk.z16; g.ldr = st.L4;
     lin16_dgrad(m, st, bk.fc2, st.gh16, st.LC, Mp, M, g, EPI_GELU_BWD, s);                         // d(z) = (d(out) Wfc2) * gelu'(z)
     memset(&g, 0, sizeof g); g.C = st.dh16; g.ldc = st.LD;
     lin16_dgrad(m, st, bk.fc1, st.dz16, st.L4, Mp, M, g, EPI_STORE_H16, s);
+    }
     sw_ln_bwd16<false, false>(st.dh16, st.LD, bk.xb16, Cs, bk.mean2, bk.rstd2, bk.ln2_g, st.gh16, st.gh16, st.LC, M, Cs, m->err_flag, s);
     memset(&g, 0, sizeof g); g.C = st.dctx16; g.ldc = st.LD;
     lin16_dgrad(m, st, bk.o, st.gh16, st.LC, Mp, M, g, EPI_STORE_H16, s);
@@ -1274,13 +1313,16 @@ int vl_swin_create(const vl_swin_config* cfg, vl_swin** out) {
     HIPCHK(hipGetDevice(&dev));
     if (int e = f32_init(dev)) return vl_fail(VL_ERR_HIP, "f32_init failed (%d)", e);
     if (cfg->reserved[0] != 0 && cfg->reserved[0] != 1) return vl_fail(VL_ERR_ARG, "precision (reserved[0]) must be 0 (f32) or 1 (f16)");
-    if (cfg->reserved[0] == 1)
+    if (cfg->reserved[0] == 1) {
         if (int e = gemm_init(dev)) return vl_fail(VL_ERR_HIP, "gemm_init: hipFuncSetAttribute failed (%d)", e);
+        if (int e = mlp_fused_init()) return vl_fail(VL_ERR_HIP, "mlp_fused_init: hipFuncSetAttribute failed (%d)", e);
+    }
     vl_swin* m = new vl_swin();
     m->cfg = *cfg;
     m->f16 = cfg->reserved[0] == 1;
     if (const char* up = getenv("VITLORA_SWIN_UNPAD")) m->unpad_stages = atoi(up);
     if (const char* pd = getenv("VITLORA_SWIN_PP_DOWN")) m->pp_down = atoi(pd);
+    if (const char* mf = getenv("VITLORA_SWIN_MLP_FUSED")) m->mlp_fused = atoi(mf);
     if (const char* fm = getenv("VITLORA_SWIN_FUSE_MERGE")) m->fuse_merge = fm[0] != '0';
     m->S = cfg->image_size; m->P = cfg->patch_size; m->G0 = m->S / m->P; m->E = cfg->embed_dim; m->C = cfg->num_labels;
     m->r = cfg->lora_targets ? cfg->lora_r : 0;
