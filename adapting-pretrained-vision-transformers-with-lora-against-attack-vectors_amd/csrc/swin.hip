@@ -528,6 +528,51 @@ void sw_ln_bwd16(const h16* dh, int ldd, const void* x, int ldx, const float* me
 #undef SWB
 }
 
+// 16-bit patch embedding of Swin (round 5; P = 4: a patch row is 4 pixels = one 16-byte fp32 load): pixels [B,3,S,S] f32 ->
+// patches [B*G*G][3*P*P = 48] h16 with (x - mean) / std fused, 8 columns (two patch rows of one channel) per thread; and the way
+// back: d(pixels)[b,c,y,x] = d(patches)[m][c*16 + ph*4 + pw] * inv_std[c] * unscale[b] (the per-image power-of-two gradient
+// scale is undone here, not in a pass of its own over the 154 MB pixel gradient)
+__global__ void patch_gather16_p4_kernel(const float* __restrict__ x, h16* __restrict__ out, int B, int S, int G, int normalise,
+                                         float m0, float m1, float m2, float is0, float is1, float is2) {
+    const int64_t total = (int64_t)B * G * G * 6, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int c8 = (int)(t % 6);
+        const int64_t mrow = t / 6;
+        const int c = c8 >> 1, ph = (c8 & 1) * 2;
+        const int b = (int)(mrow / (G * G)), pi = (int)(mrow - (int64_t)b * G * G);
+        const int py = pi / G, px = pi - py * G;
+        const float* src = x + (((int64_t)b * 3 + c) * S + py * 4 + ph) * S + px * 4;
+        const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + S);
+        float mean = 0.f, is = 1.f;
+        if (normalise) { mean = c == 0 ? m0 : (c == 1 ? m1 : m2); is = c == 0 ? is0 : (c == 1 ? is1 : is2); }
+        sh16x8 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o[i] = f2h((v0[i] - mean) * is); o[4 + i] = f2h((v1[i] - mean) * is); }
+        *(sh16x8*)(out + mrow * 48 + c8 * 8) = o;
+    }
+}
+__global__ void patch_scatter16_p4_kernel(const h16* __restrict__ dp, float* __restrict__ gx, int B, int S, int G, float is0,
+                                          float is1, float is2, const float* __restrict__ unscale, int* __restrict__ err) {
+    const int64_t total = (int64_t)B * G * G * 6, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int c8 = (int)(t % 6);
+        const int64_t mrow = t / 6;
+        const int c = c8 >> 1, ph = (c8 & 1) * 2;
+        const int b = (int)(mrow / (G * G)), pi = (int)(mrow - (int64_t)b * G * G);
+        const int py = pi / G, px = pi - py * G;
+        const sh16x8 v = *(const sh16x8*)(dp + mrow * 48 + c8 * 8);
+        const float f = (c == 0 ? is0 : (c == 1 ? is1 : is2)) * (unscale ? unscale[b] : 1.f);
+        f32x4 o0, o1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o0[i] = (float)v[i] * f; o1[i] = (float)v[4 + i] * f; }
+        if (err && !(fabsf(o0[0]) < INFINITY && fabsf(o0[1]) < INFINITY && fabsf(o0[2]) < INFINITY && fabsf(o0[3]) < INFINITY &&
+                     fabsf(o1[0]) < INFINITY && fabsf(o1[1]) < INFINITY && fabsf(o1[2]) < INFINITY && fabsf(o1[3]) < INFINITY)) *err = 2;
+        float* dst = gx + (((int64_t)b * 3 + c) * S + py * 4 + ph) * S + px * 4;
+        *(f32x4*)dst = o0;
+        *(f32x4*)(dst + S) = o1;
+    }
+}
+
 // The unpadded stages' h16 activations have rows NARROWER than the padded K of the GEMM that reads them: the last valid row's
 // K tail is read from the first bytes of the row after it, against zero weight columns.  That row is never written (a pad row,
 // or the 512-byte slack behind the buffer), so these 256-byte heads are zeroed at the start of every forward: 0 x garbage would
@@ -1057,6 +1102,10 @@ struct vl_swin {
     int* err_flag = nullptr;
     float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
     float *gscale = nullptr, *inv_gscale = nullptr, *dlogits_s = nullptr;
+    h16 *Wpe16 = nullptr, *WpeT16 = nullptr;      // 16-bit patch embedding (P = 4): [128][64] (rows >= E, columns >= 48 zero), [128][128] (rows >= 48 zero)
+    float* bpe16 = nullptr;                        // [128] fp32, zero padded
+    h16 *patches16 = nullptr, *emb16 = nullptr;    // [R0][48], [R0][E]
+    int pe16 = 0;                                  // the 16-bit patch embedding is in use (P == 4, E <= 128; VITLORA_SWIN_PE16=0: fp32 form of rounds 3-4)
     h16 *xlast16 = nullptr, *hfin16 = nullptr, *dhfin16 = nullptr;      // 16-bit path: last stage's output stream, final LayerNorm output, its gradient
     int f16 = 0;             // cfg.reserved[0] == 1: 16-bit operand path for the blocks (embedding, merging and head stay fp32)
     int dirty = 1;           // packed h16 operands are stale (weights / adapters written since the last commit)
@@ -1148,6 +1197,12 @@ void swin16_commit(vl_swin* m, hipStream_t s) {
                     k_pack_h16_t(sl.A, ln->Au, m->r, ln->in, 64, eo, m->scaling, s);
                 }
             }
+    if (m->pe16) {
+        const int PK = 3 * m->P * m->P;
+        k_pack_h16(m->Wpe, m->Wpe16, m->E, PK, 64, 0, 1.f, s);
+        k_pack_h16_t(m->Wpe, m->WpeT16, m->E, PK, 128, 0, 1.f, s);
+        (void)hipMemcpyAsync(m->bpe16, m->bpe, (size_t)m->E * sizeof(float), hipMemcpyDeviceToDevice, s);
+    }
     for (int i = 0; i < 3; ++i) {
         SStage& st = m->stages[i];
         k_pack_h16(st.Wred, st.Wred16, 2 * st.C, 4 * st.C, 4 * st.C, 0, 1.f, s);
@@ -1331,6 +1386,9 @@ int vl_swin_create(const vl_swin_config* cfg, vl_swin** out) {
 #define A_(p, n) if ((rc = salloc(m, &(p), (size_t)(n))) != VL_OK) { vl_swin_destroy(m); return rc; }
     const int PK = 3 * m->P * m->P;
     A_(m->Wpe, (size_t)m->E * PK); A_(m->bpe, m->E); A_(m->eg, m->E); A_(m->eb, m->E);
+    m->pe16 = m->f16 && m->P == 4 && m->E <= 128 && m->E % 32 == 0;
+    if (const char* pe = getenv("VITLORA_SWIN_PE16")) m->pe16 = m->pe16 && atoi(pe) != 0;
+    if (m->pe16) { A_(m->Wpe16, (size_t)128 * 64); A_(m->WpeT16, (size_t)128 * 128); A_(m->bpe16, 128); }
     // flat LoRA buffer layout: [stage][block][target q,k,v,o,fc1,fc2]{A, B}
     int64_t off = 0;
     m->stages.resize(4);
@@ -1497,6 +1555,10 @@ static size_t swin_carve(vl_swin* m, int B, char* base) {
     const int L0 = m->G0 * m->G0, PK = 3 * m->P * m->P;
     const int64_t R0 = round_up((int64_t)B * L0, 64);
     m->patches = take((size_t)R0 * PK * 4);
+    if (m->pe16) {       // (rows rounded up to the GEMM's 128-row tiles: the projection reads and stores whole tiles)
+        const int64_t R128 = round_up((int64_t)B * L0, 128);
+        m->patches16 = (h16*)take((size_t)R128 * PK * 2 + 512); m->emb16 = (h16*)take((size_t)R128 * m->E * 2 + 512);
+    }
     m->emb = take((size_t)R0 * m->E * 4); m->emean = take((size_t)R0 * 4); m->erstd = take((size_t)R0 * 4);
     size_t big = 0;
     for (int i = 0; i < 4; ++i) {
@@ -1589,23 +1651,40 @@ static int swin_forward(vl_swin* m, const float* x, int B, int normalise, hipStr
     const int L0 = m->G0 * m->G0, PK = 3 * m->P * m->P;
     if (m->f16 && m->dirty) swin16_commit(m, s);
     // patch embedding: Conv2d(3, E, k = s = P) as a GEMM over gathered patches, then LayerNorm (SwinEmbeddings)
-    k_patch_gather_f32(x, m->patches, B, m->S, m->P, normalise, m->mean, m->stdv, s);
-    GemmF32 g = gm(m->patches, PK, m->Wpe, PK, 0, B * L0, m->E, PK, m->emb, m->E);
-    g.bias = m->bpe;
-    k_gemm_f32(g, s);
-    if (m->f16) {
-        // ---- 16-bit path (round 5: h16 residual streams; the embedding LayerNorm's output IS the stream of stage 1) ----
-        sw_ln_fwd16<true>(m->emb, m->E, nullptr, 0, nullptr, 0, m->stages[0].blocks[0].xa16, m->E, m->emean, m->erstd, m->eg, m->eb,
-                          B * L0, m->E, m->cfg.ln_eps, m->err_flag, s);
-        {   // K-tail heads of the unpadded stages' GEMM A operands (zero_tails_kernel)
+    if (m->f16) {   // K-tail heads of the unpadded stages' GEMM A operands (zero_tails_kernel)
             TailPtrs tp; tp.n = 0;
             for (SStage& st : m->stages) {
                 const int64_t Mi = (int64_t)B * st.H * st.H;
                 if (st.LC < st.CP) { tp.p[tp.n++] = st.h16b + Mi * st.LC; tp.p[tp.n++] = st.ctx16 + Mi * st.LC; tp.p[tp.n++] = st.gh16 + Mi * st.LC; }
                 if (st.L3 < st.C3P) tp.p[tp.n++] = st.dqkv16 + Mi * st.L3;
             }
+            if (m->pe16) {      // patches (48 of the 64-deep K tile)
+                tp.p[tp.n++] = m->patches16 + (int64_t)B * L0 * PK;
+                // (the embedding gradient is staged in stage 1's h16b -- never a GEMM result, so its pad rows hold nothing but these zeros)
+            }
             if (tp.n) hipLaunchKernelGGL(zero_tails_kernel, dim3(tp.n), dim3(64), 0, s, tp);
         }
+    if (m->pe16) {
+        // 16-bit patch embedding: h16 patches [B L0][48] (K tail of the 64-deep tile read from the next row against zero weight
+        // columns), projection on the streaming GEMM, h16 result of width E
+        hipLaunchKernelGGL(patch_gather16_p4_kernel, dim3(nblk((int64_t)B * L0 * 6, 256, 8192)), dim3(256), 0, s, x, m->patches16, B, m->S, m->G0,
+                           normalise, m->mean[0], m->mean[1], m->mean[2], 1.f / m->stdv[0], 1.f / m->stdv[1], 1.f / m->stdv[2]);
+        GemmArgs ge = ga(m->patches16, PK, m->Wpe16, 64, 64, (int)round_up((int64_t)B * L0, 128), 128);
+        ge.Mvalid = B * L0; ge.bias = m->bpe16; ge.C = m->emb16; ge.ldc = m->E; ge.n_store = m->E; ge.n_algo = m->E;
+        launch_gemm(ge, EPI_STORE_H16, 128, s);
+    } else {
+    k_patch_gather_f32(x, m->patches, B, m->S, m->P, normalise, m->mean, m->stdv, s);
+    GemmF32 g = gm(m->patches, PK, m->Wpe, PK, 0, B * L0, m->E, PK, m->emb, m->E);
+    g.bias = m->bpe;
+    k_gemm_f32(g, s);
+    }
+    if (m->f16) {
+        // ---- 16-bit path (round 5: h16 residual streams; the embedding LayerNorm's output IS the stream of stage 1) ----
+        if (m->pe16) sw_ln_fwd16<false>(m->emb16, m->E, nullptr, 0, nullptr, 0, m->stages[0].blocks[0].xa16, m->E, m->emean, m->erstd, m->eg,
+                                        m->eb, B * L0, m->E, m->cfg.ln_eps, m->err_flag, s);
+        else
+        sw_ln_fwd16<true>(m->emb, m->E, nullptr, 0, nullptr, 0, m->stages[0].blocks[0].xa16, m->E, m->emean, m->erstd, m->eg, m->eb,
+                          B * L0, m->E, m->cfg.ln_eps, m->err_flag, s);
         for (int i = 0; i < 4; ++i) {
             SStage& st = m->stages[i];
             const int Cs = st.C, Hs = st.H, M = B * Hs * Hs;
@@ -1723,11 +1802,24 @@ static int swin_backward(vl_swin* m, float* grad_x, hipStream_t s) {
         if (grad_x) {
             const int L0 = m->G0 * m->G0, PK = 3 * m->P * m->P;
             // embedding LayerNorm backward (x = the fp32 patch-embedding output) -> fp32, then the patch projection's dgrad in fp32
+            float is[3];
+            for (int c = 0; c < 3; ++c) is[c] = m->cur_norm ? 1.f / m->stdv[c] : 1.f;
+            if (m->pe16) {
+                // embedding LayerNorm backward on h16 (its result in stage 1's h16b, free by now), the projection's dgrad on the
+                // streaming GEMM (h16 d(patches) over the forward's patches), then ONE scatter to pixels that also undoes the scale
+                h16* gemb = m->stages[0].h16b;       // (a LayerNorm-output buffer: rows >= M are never written, its K-tail head is zeroed per forward)
+                sw_ln_bwd16<false, false>(m->stages[0].gh16, m->stages[0].LC, m->emb16, m->E, m->emean, m->erstd, m->eg, nullptr, gemb, m->E,
+                                          B * L0, m->E, m->err_flag, s);
+                GemmArgs gd = ga(gemb, m->E, m->WpeT16, 128, 128, (int)round_up((int64_t)B * L0, 128), 128);
+                gd.Mvalid = B * L0; gd.C = m->patches16; gd.ldc = PK; gd.n_store = PK; gd.n_algo = PK;
+                launch_gemm(gd, EPI_STORE_H16, 128, s);
+                hipLaunchKernelGGL(patch_scatter16_p4_kernel, dim3(nblk((int64_t)B * L0 * 6, 256, 8192)), dim3(256), 0, s, m->patches16, grad_x, B, m->S,
+                                   m->G0, is[0], is[1], is[2], m->inv_gscale, m->err_flag);
+                return VL_OK;
+            }
             sw_ln_bwd16<true, true>(m->stages[0].gh16, m->stages[0].LC, m->emb, m->E, m->emean, m->erstd, m->eg, nullptr, m->g1, m->E,
                                     B * L0, m->E, m->err_flag, s);
             k_gemm_f32(gm(m->g1, m->E, m->Wpe, PK, 1, B * L0, PK, m->E, m->patches, PK), s);
-            float is[3];
-            for (int c = 0; c < 3; ++c) is[c] = m->cur_norm ? 1.f / m->stdv[c] : 1.f;
             k_patch_scatter_f32(m->patches, grad_x, B, m->S, m->P, is, s);
             // undo the per-image gradient scale
             hipLaunchKernelGGL(scale_rows_kernel, dim3(8192), dim3(256), 0, s, grad_x, m->inv_gscale, grad_x, B, (int64_t)3 * m->S * m->S);
