@@ -50,6 +50,8 @@ struct GemmArgs {
     // rows][K1] h16 (the rows of Ad in use, zero padded), down_out (optional) receives t (ld = down_ld); A2 is then unused
     const h16* down_W; int down_ldw; h16* down_out; int down_ld; int down_groups;
     int ones_col;     // gemm_pp with the down projection inside: column 63 of the LoRA K tile is set to 1 (W2 column 63 = the bias, `bias` null)
+    int no_pp;        // 1: never the ping-pong kernel (the Swin stages 3-4 shapes -- M = 50 176 / 12 544 rows, N = 512 .. 3 072 -- run 1.5 % of a step
+                      // faster on the 256-row kernel: 17.30 vs 17.56 ms, same box, round 5)
     int tile_group;   // gemm256: tile rows per group of the tile walk (0 = 8 for N >= 2048, else 1; 1 = row-major, the round-1 order)
     int dephase;      // gemm256: start offset unit (x 8128 cycles x (workgroup/8 mod 4)); 0 = off
     // EPI_DROP_ACC: dropout mask of element (m, n) of the module input = drop_scale(seed, stream, m*N + n)

@@ -223,7 +223,7 @@ void launch_gemm(const GemmArgs& a, int epi, int bn, hipStream_t s) {
         return;
     }
     const bool narrow = a.n_store > 0 && a.n_store < a.N;      // only the 128-row kernel skips columns
-    if (bn != 64 && g_force_small != 1 && !narrow && gemm_pp_supports(a, epi)) {
+    if (bn != 64 && g_force_small != 1 && !narrow && !a.no_pp && gemm_pp_supports(a, epi)) {
         launch_gemm_pp(a, epi, s);
         return;
     }

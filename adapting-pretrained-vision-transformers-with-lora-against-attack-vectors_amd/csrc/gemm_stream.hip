@@ -309,7 +309,7 @@ int g_stream_cus = 0;
 int g_stream_on = 1;            // VITLORA_GEMM_STREAM=0: every such product on gemm_nt_kernel
 int g_stream_min_rows = 65536;  // tall ...
 int g_stream_min_rows64 = 8192;  // (the 64-column form: the LoRA down products that stay separate launches)
-int g_stream_max_k = 640;       // ... and shallow
+int g_stream_max_k = 832;       // ... and shallow (round 5: 640 -> 832 takes Swin stage 2's K = 768 + LoRA tile products from the 128 x 128 kernel: -0.2 ms per step)
 int g_stream_down = 1;          // VITLORA_GEMM_STREAM_DOWN=0: LoRA down projections stay separate launches
 
 template <int BN, int EPI, bool DOWN = false>

@@ -1214,7 +1214,7 @@ void swin16_commit(vl_swin* m, hipStream_t s) {
 // y = x W^T + b (+ LoRA as one extra K tile), epilogue `epi`; x [Mp][inP] h16
 void lin16_fwd(vl_swin* m, SStage& st, const SLin& ln, const h16* x, int ldx, int Mp, int M, GemmArgs g, int epi, hipStream_t s) {
     g.A1 = x; g.lda1 = ldx; g.W1 = ln.W16; g.ldw1 = ln.inP; g.K1 = ln.inP;
-    g.M = Mp; g.Mvalid = M; g.N = ln.outN; g.bias = ln.b16;
+    g.M = Mp; g.Mvalid = M; g.N = ln.outN; g.bias = ln.b16; g.no_pp = m->pp_down ? 0 : 1;
     g.n_store = g.ldc < ln.outN ? ln.out : 0;                      // unpadded result rows (ldc = out)
     if (ln.kext) {
         g.W2 = ln.Bu; g.ldw2 = 64; g.K2 = 64;
@@ -1236,7 +1236,7 @@ void lin16_fwd(vl_swin* m, SStage& st, const SLin& ln, const h16* x, int ldx, in
 // dx = dy W (+ LoRA), dy [Mp][outP] h16
 void lin16_dgrad(vl_swin* m, SStage& st, const SLin& ln, const h16* dy, int ldy, int Mp, int M, GemmArgs g, int epi, hipStream_t s) {
     g.A1 = dy; g.lda1 = ldy; g.W1 = ln.WT16; g.ldw1 = ln.outP; g.K1 = ln.outP;
-    g.M = Mp; g.Mvalid = M; g.N = ln.inN; g.bias = nullptr;
+    g.M = Mp; g.Mvalid = M; g.N = ln.inN; g.bias = nullptr; g.no_pp = m->pp_down ? 0 : 1;
     g.n_store = g.ldc < ln.inN ? ln.in : 0;
     if (ln.kext) {
         g.W2 = ln.Au; g.ldw2 = 64; g.K2 = 64;
