@@ -8,6 +8,7 @@
 //     (table[(dy+6)*13 + (dx+6)][head]) are evaluated on the fly;
 //   * one wave per (image, window, head): lane = query (forward, dQ) or key (dK, dV); 49 tokens, head_dim 32.
 // This is the functional first form of the path (parity first); an fp16 MFMA form of the window kernels is the next step.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1110,6 +1111,15 @@ struct vl_swin {
     int f16 = 0;             // cfg.reserved[0] == 1: 16-bit operand path for the blocks (embedding, merging and head stay fp32)
     int dirty = 1;           // packed h16 operands are stale (weights / adapters written since the last commit)
     int fuse_merge = 1;      // VITLORA_SWIN_FUSE_MERGE=0: separate materialise / gather / LayerNorm / pack passes around the merges
+    // vl_swin_pgd_attack as TWO half-batch chains on two streams (round 5; the ViT path got them in round 4): stages 3-4 are
+    // small-batch shaped at any batch (M = 50 176 / 12 544 rows: 392 / 147 tiles on 256 CUs) and the window kernels run one or two waves
+    // per SIMD, so the ends of one chain's kernels meet the main loops of the other's.  The chains are shallow copies of the handle
+    // (shared weights) whose workspace pointers are carved into the SAME planned bytes as the main workspace (never live together).
+    static constexpr int MAXCH = 4;
+    vl_swin* chain[MAXCH] = {nullptr, nullptr, nullptr, nullptr};
+    int chain_batch = 0, chains_on = 2, chain_min = 32;      // VITLORA_SWIN_CHAINS = number of chains (0 / 1: off, default 2, at most 4); VITLORA_SWIN_CHAIN_MIN: smallest batch that is split
+    hipStream_t side[MAXCH - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int mlp_fused = 0;       // VITLORA_SWIN_MLP_FUSED=1: stage 1's MLP (fc1 -> GELU -> fc2, and its backward) in ONE kernel with the hidden activation in
                              // LDS (csrc/mlp_fused.hip).  Built, tested and measured in round 5 and NOT the default: it removes 2.0 GB of HBM traffic per
                              // block and is SLOWER (660 + 533 us against 491 + 462 us for the two-launch forms at batch 256): these products are bound
@@ -1378,6 +1388,8 @@ int vl_swin_create(const vl_swin_config* cfg, vl_swin** out) {
     if (const char* up = getenv("VITLORA_SWIN_UNPAD")) m->unpad_stages = atoi(up);
     if (const char* pd = getenv("VITLORA_SWIN_PP_DOWN")) m->pp_down = atoi(pd);
     if (const char* mf = getenv("VITLORA_SWIN_MLP_FUSED")) m->mlp_fused = atoi(mf);
+    if (const char* ch = getenv("VITLORA_SWIN_CHAINS")) m->chains_on = std::min(atoi(ch), (int)vl_swin::MAXCH);
+    if (const char* cm = getenv("VITLORA_SWIN_CHAIN_MIN")) m->chain_min = atoi(cm);
     if (const char* fm = getenv("VITLORA_SWIN_FUSE_MERGE")) m->fuse_merge = fm[0] != '0';
     m->S = cfg->image_size; m->P = cfg->patch_size; m->G0 = m->S / m->P; m->E = cfg->embed_dim; m->C = cfg->num_labels;
     m->r = cfg->lora_targets ? cfg->lora_r : 0;
@@ -1458,8 +1470,16 @@ int vl_swin_create(const vl_swin_config* cfg, vl_swin** out) {
     return VL_OK;
 }
 
+static void swin_drop_chains(vl_swin* m) {
+    for (int c = 0; c < vl_swin::MAXCH; ++c) { delete m->chain[c]; m->chain[c] = nullptr; }      // (non-owning copies: no device memory of their own)
+    m->chain_batch = 0;
+}
 int vl_swin_destroy(vl_swin* m) {
     if (!m) return VL_OK;
+    swin_drop_chains(m);
+    for (hipStream_t sd : m->side) if (sd) (void)hipStreamDestroy(sd);
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->err_flag) (void)hipHostFree(m->err_flag);
     delete m;
@@ -1617,6 +1637,21 @@ static size_t swin_carve(vl_swin* m, int B, char* base) {
     return off;
 }
 
+// chain workspaces: each for ceil(max_batch / 2) images, carved into the same bytes as the main workspace
+static int swin_chain_images(const vl_swin* m, int max_batch) {
+    const int nc = m->chains_on;
+    return (m->f16 && nc >= 2 && max_batch >= m->chain_min && max_batch >= nc) ? (max_batch + nc - 1) / nc : 0;
+}
+static size_t swin_plan_bytes(vl_swin* m, int max_batch) {
+    const size_t main_need = swin_carve(m, max_batch, nullptr);
+    const int cb = swin_chain_images(m, max_batch);
+    if (!cb) return main_need;
+    vl_swin tmp(*m);
+    tmp.allocs.clear();
+    const size_t one = swin_carve(&tmp, cb, nullptr);
+    return std::max(main_need, (size_t)m->chains_on * one);
+}
+
 int vl_swin_plan(vl_swin* m, int max_batch, size_t* bytes) {
     if (!m || !bytes || max_batch <= 0) return vl_fail(VL_ERR_ARG, "bad argument");
     if (m->f16) {
@@ -1627,7 +1662,7 @@ int vl_swin_plan(vl_swin* m, int max_batch, size_t* bytes) {
             return vl_fail(VL_ERR_UNSUPPORTED, "max_batch %d: an activation of %lld x %lld 16-bit elements exceeds the 4 GiB the kernels' "
                            "32-bit operand offsets reach; split the batch", max_batch, (long long)rows, (long long)wide);
     }
-    *bytes = swin_carve(m, max_batch, nullptr);
+    *bytes = swin_plan_bytes(m, max_batch);
     m->max_batch = -max_batch;          // planned, not armed
     return VL_OK;
 }
@@ -1637,12 +1672,31 @@ int vl_swin_set_workspace(vl_swin* m, void* ws, size_t bytes) {
     if (m->max_batch >= 0) return vl_fail(VL_ERR_STATE, "vl_swin_set_workspace before vl_swin_plan");
     const int B = -m->max_batch;
     if (((uintptr_t)ws) & 255) return vl_fail(VL_ERR_ARG, "workspace must be 256-byte aligned");
-    const size_t need = swin_carve(m, B, nullptr);
+    const size_t need = swin_plan_bytes(m, B);
     if (bytes < need) return vl_fail(VL_ERR_ARG, "workspace too small: %zu < %zu", bytes, need);
     swin_carve(m, B, (char*)ws);
     if (hipMemset(ws, 0, need) != hipSuccess) return vl_fail(VL_ERR_HIP, "hipMemset(workspace) failed");
     m->max_batch = B;
     m->cur_B = 0;
+    swin_drop_chains(m);
+    if (const int cb = swin_chain_images(m, B)) {
+        size_t one = 0;
+        for (int c = 0; c < m->chains_on; ++c) {
+            vl_swin* ch = new vl_swin(*m);          // weights shared (pointers), workspace pointers re-carved below
+            ch->allocs.clear(); ch->ev_fork = ch->ev_join = nullptr;
+            for (int k = 0; k < vl_swin::MAXCH; ++k) ch->chain[k] = nullptr;
+            for (int k = 0; k < vl_swin::MAXCH - 1; ++k) ch->side[k] = nullptr;
+            one = swin_carve(ch, cb, nullptr);
+            swin_carve(ch, cb, (char*)ws + (size_t)c * one);
+            ch->max_batch = cb; ch->cur_B = 0; ch->have_loss = 0;
+            m->chain[c] = ch;
+        }
+        m->chain_batch = cb;
+        for (int k = 0; k + 1 < m->chains_on; ++k)
+            if (!m->side[k]) HIPCHK(hipStreamCreateWithFlags(&m->side[k], hipStreamNonBlocking));
+        if (!m->ev_fork) HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+        if (!m->ev_join) HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    }
     return VL_OK;
 }
 
@@ -1920,6 +1974,47 @@ int vl_swin_pgd_attack(vl_swin* m, const float* x0, const int64_t* labels, int b
     int rc = swin_check(m);
     if (rc) return rc;
     const int64_t n = (int64_t)batch * 3 * m->S * m->S;
+    if (m->chain_batch && batch >= m->chain_min && batch >= m->chains_on && steps > 0) {
+        // ---- two half-batch chains (see the handle): images are independent, the halves run on s and on the side stream ----
+        const int NC = m->chains_on;
+        int bsz[vl_swin::MAXCH], first[vl_swin::MAXCH];
+        for (int c = 0, at = 0; c < NC; ++c) { bsz[c] = batch / NC + (c < batch % NC ? 1 : 0); first[c] = at; at += bsz[c]; }
+        const int64_t img = (int64_t)3 * m->S * m->S;
+        if (m->f16 && m->dirty) { swin16_commit(m, s); }
+        for (int c = 0; c < NC; ++c) {
+            vl_swin* ch = m->chain[c];
+            ch->dirty = 0; ch->mean[0] = m->mean[0]; ch->mean[1] = m->mean[1]; ch->mean[2] = m->mean[2];
+            ch->stdv[0] = m->stdv[0]; ch->stdv[1] = m->stdv[1]; ch->stdv[2] = m->stdv[2];
+            HIPCHK(hipMemcpyAsync(ch->stage_x0, x0 + first[c] * img, (size_t)bsz[c] * img * sizeof(float), hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync(ch->stage_labels, labels + first[c], (size_t)bsz[c] * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+        }
+        // the random start is a function of (seed, element index of the WHOLE batch): drawn once into the caller's buffer
+        if (random_start) k_pgd_init(adv_out, x0, eps, 0.f, 1.f, seed, n, s);
+        else if (adv_out != x0) HIPCHK(hipMemcpyAsync(adv_out, x0, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        for (int c = 0; c < NC; ++c)
+            HIPCHK(hipMemcpyAsync(m->chain[c]->stage_adv, adv_out + first[c] * img, (size_t)bsz[c] * img * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipEventRecord(m->ev_fork, s));
+        for (int c = 1; c < NC; ++c) HIPCHK(hipStreamWaitEvent(m->side[c - 1], m->ev_fork, 0));
+        for (int i = 0; i < steps; ++i)
+            for (int c = 0; c < NC; ++c) {
+                vl_swin* ch = m->chain[c];
+                hipStream_t sc = c ? m->side[c - 1] : s;
+                const int64_t nc = (int64_t)bsz[c] * img;
+                if ((rc = swin_forward(ch, ch->stage_adv, bsz[c], 1, sc))) return rc;
+                k_ce_loss(ch->logits, ch->stage_labels, bsz[c], ch->C, ch->dlogits, ch->loss_img, ch->loss, ch->err_flag, sc);
+                ch->have_loss = 1;
+                if ((rc = swin_backward(ch, ch->grad_img, sc))) return rc;
+                k_pgd_step(ch->stage_adv, ch->stage_x0, ch->grad_img, eps, alpha, 0.f, 1.f, nc, sc, ch->err_flag);
+            }
+        for (int c = 1; c < NC; ++c) {
+            HIPCHK(hipEventRecord(m->ev_join, m->side[c - 1]));
+            HIPCHK(hipStreamWaitEvent(s, m->ev_join, 0));
+        }
+        for (int c = 0; c < NC; ++c)
+            HIPCHK(hipMemcpyAsync(adv_out + first[c] * img, m->chain[c]->stage_adv, (size_t)bsz[c] * img * sizeof(float), hipMemcpyDeviceToDevice, s));
+        m->cur_B = 0; m->have_loss = 0;        // the main workspace shares its bytes with the chains: no forward of the whole batch is held
+        return swin_launch_ok("vl_swin_pgd_attack");
+    }
     HIPCHK(hipMemcpyAsync(m->stage_x0, x0, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(m->stage_labels, labels, (size_t)batch * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     if (random_start) k_pgd_init(m->stage_adv, m->stage_x0, eps, 0.f, 1.f, seed, n, s);

@@ -270,6 +270,10 @@ int vl_swin_set_workspace(vl_swin* m, void* ws, size_t bytes);
 int vl_swin_forward(vl_swin* m, const float* x, int batch, int normalise, float* logits_out, void* stream);
 int vl_swin_loss_ce(vl_swin* m, const int64_t* labels, float* loss_out, void* stream);
 int vl_swin_backward_input(vl_swin* m, float* grad_x_out, void* stream);
+/* Batches of >= 32 images run as TWO half-batch chains on two streams (the caller's and an internal one that forks after the staging
+ * copies and joins before the result is copied out); the chains' workspaces share the planned bytes with the main workspace, so a
+ * forward held for vl_swin_backward_input does not survive an attack (the handle then reports "backward before loss").  Bit-identical
+ * to one chain; VITLORA_SWIN_CHAINS=0 (environment, read at vl_swin_create) restores the single chain. */
 int vl_swin_pgd_attack(vl_swin* m, const float* x0, const int64_t* labels, int batch, float eps, float alpha, int steps,
                        int random_start, uint64_t seed, float* adv_out, void* stream);
 /* vl_check_errors for a Swin handle (same codes: VL_ERR_ARG bad label, VL_ERR_NONFINITE fp16 gradient out of range). */

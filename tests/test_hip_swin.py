@@ -179,6 +179,38 @@ def test_swin_fp16_backward_out_of_range_is_flagged_as_nonfinite_not_as_a_bad_la
     assert torch.isfinite(g32).all()
 
 
+def test_swin_two_chain_attack_equals_the_single_chain_attack(monkeypatch):
+    """vl_swin_pgd_attack runs batches of >= 32 images as two half-batch chains on two streams (round 5; shallow copies of the
+    handle whose workspaces share the planned bytes).  Images are independent and 1/B differs by a power of two between the forms,
+    so the chained result must be the single-chain result bit for bit -- here at batch 8 (threshold lowered to 2) with LoRA,
+    random start (drawn over the whole batch in both forms) and at an odd batch 7 (4 + 3: 1/B is no power-of-two multiple, so only
+    agreement to rounding is asked there); a forward / backward pair after a chained attack works on the main workspace again."""
+    depths = (1, 1, 2, 1)
+    m = hf_swin(12, seed=41, depths=depths)
+    ab = add_lora(m, 8, 16.0, seed=42)
+    g = torch.Generator().manual_seed(43)
+    x = torch.rand(8, 3, 224, 224, generator=g).cuda()
+    y = torch.randint(0, 12, (8,), generator=g).cuda()
+    outs = {}
+    for mode in ("0", "2", "3"):
+        monkeypatch.setenv("VITLORA_SWIN_CHAINS", mode)
+        monkeypatch.setenv("VITLORA_SWIN_CHAIN_MIN", "2")
+        eng = make_engine(m, 12, 8, ab, depths=depths, precision="f16")
+        a8 = eng.pgd_attack(x, y, 8 / 255, 2 / 255, 3, random_start=True, seed=5).clone()
+        a7 = eng.pgd_attack(x[:7].contiguous(), y[:7].contiguous(), 8 / 255, 2 / 255, 3, random_start=False).clone()
+        logits = eng.forward(x, normalise=True).clone()          # the main workspace after a chained attack
+        eng.loss_ce(y)
+        gx = eng.backward_input(tuple(x.shape)).clone()
+        eng.check()
+        torch.cuda.synchronize()
+        outs[mode] = (a8.cpu(), a7.cpu(), logits.cpu(), gx.cpu())
+        del eng
+    assert torch.equal(outs["0"][0], outs["2"][0]), float((outs["0"][0] != outs["2"][0]).float().mean())
+    for k in ("2", "3"):           # 4 + 3 and 3 + 3 + 2 / 3 + 2 + 2 images: 1 / B is no power-of-two multiple of the single chain's
+        assert float((outs["0"][0] == outs[k][0]).float().mean()) > 0.995 and float((outs["0"][1] == outs[k][1]).float().mean()) > 0.995
+        assert torch.equal(outs["0"][2], outs[k][2]) and torch.equal(outs["0"][3], outs[k][3])
+
+
 def test_swin_fused_mlp_kernel_agrees_with_the_two_gemm_form(monkeypatch):
     """csrc/mlp_fused.hip (round 5): stage 1's fc1 -> GELU -> fc2 (forward) and fc2 dgrad -> * gelu' -> fc1 dgrad (backward) in
     one kernel each, the hidden activation kept in LDS (an experiment that is not the default: it removes the HBM traffic and is
