@@ -1026,8 +1026,9 @@ __global__ __launch_bounds__(64) void win16_bwd_kernel(const h16* __restrict__ q
 }
 
 // persistent grid of the window kernels: `per_cu` single-wave workgroups per CU, a multiple of `heads`, at most one per item
+int g_win_cus = 256;       // VITLORA_SWIN_WIN_CUS: CUs a window-attention launch is sized for (A/B knob: half the chip per chain when two chains run)
 inline unsigned win16_grid(int64_t items, int heads, int per_cu) {
-    int64_t wn = (int64_t)256 * per_cu / heads * heads;
+    int64_t wn = (int64_t)g_win_cus * per_cu / heads * heads;
     if (wn > items) wn = items;          // items is a multiple of heads
     return (unsigned)wn;
 }
@@ -1390,6 +1391,7 @@ int vl_swin_create(const vl_swin_config* cfg, vl_swin** out) {
     if (const char* mf = getenv("VITLORA_SWIN_MLP_FUSED")) m->mlp_fused = atoi(mf);
     if (const char* ch = getenv("VITLORA_SWIN_CHAINS")) m->chains_on = std::min(atoi(ch), (int)vl_swin::MAXCH);
     if (const char* cm = getenv("VITLORA_SWIN_CHAIN_MIN")) m->chain_min = atoi(cm);
+    if (const char* wc = getenv("VITLORA_SWIN_WIN_CUS")) g_win_cus = atoi(wc);
     if (const char* fm = getenv("VITLORA_SWIN_FUSE_MERGE")) m->fuse_merge = fm[0] != '0';
     m->S = cfg->image_size; m->P = cfg->patch_size; m->G0 = m->S / m->P; m->E = cfg->embed_dim; m->C = cfg->num_labels;
     m->r = cfg->lora_targets ? cfg->lora_r : 0;
