@@ -307,3 +307,31 @@ def test_integration_md_indexes_every_abi_symbol():
     listed = set(re.findall(r"`(vl_[a-z0-9_]+)`", sec))
     assert syms - listed == set(), sorted(syms - listed)
     assert listed - syms == set(), sorted(listed - syms)
+
+
+def test_adam_drop_last_step_and_bench_flop_accounting():
+    """Host logic added in round 5 (no GPU): (i) `optim.Adam.drop_last_step` takes a dropped optimizer step out of the
+    bias-correction count, as an AMP skip-step never calls `optimizer.step()` (train_loras.py:314; round-4 ADVICE); (ii) the
+    bench's algorithmic-FLOP functions: ViT-B/16 + LoRA r = 8 on q,k,v,o,fc2 = 72.438 GFLOP per image per PGD step
+    and Swin-T + LoRA r = 16 = 19.43 (HF SwinConfig() shapes: 2 x 4.5 GMAC forward, dgrad once more, windowed attention x 2)."""
+    import types
+    optim = importlib.import_module(PKG + ".optim")
+    p = torch.nn.Parameter(torch.zeros(8))
+    opt = optim.Adam([p], lr=1e-3, model=None, distributed=False)
+    opt.t = 5
+    opt.drop_last_step()
+    assert opt.t == 4
+    opt.t = 0
+    opt.drop_last_step()
+    assert opt.t == 0                                       # never negative
+    sys.path.insert(0, ROOT)
+    import bench
+    P = importlib.import_module(PKG)
+    fl = bench.algorithmic_flops_per_image_step(P.ArchConfig(num_labels=21), 8, bench.TARGETS)
+    assert abs(fl / 1e9 - 72.438) < 0.01, fl
+    swin = importlib.import_module(PKG + ".swin")
+    fs = bench.swin_flops_per_image_step(swin.SwinArch(num_labels=21), 16, bench.TARGETS)
+    assert 19.0 < fs / 1e9 < 19.9, fs
+    # forward alone without LoRA: 2 x the 4.35 GMAC the Swin paper quotes for Swin-T's linears + attention (4.5 GFLOPs "multiply-adds")
+    f0 = bench.swin_flops_per_image_step(swin.SwinArch(num_labels=21), 0, ()) / 2
+    assert 8.4e9 < f0 < 9.4e9, f0
