@@ -474,6 +474,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, int ntil
 int g_pp_cus = 0;
 int g_pp_mode = 2;          // VITLORA_GEMM_PP: 0 = off, 1 = every supported GEMM, 2 = the shapes it wins on (plain 16-bit stores, K <= 2304)
 int g_pp_attr_err = 0;
+int g_pp_max_k = 2304;      // VITLORA_GEMM_PP_MAXK: deepest plain-store product sent here in mode 2
 
 template <int EPI, int ND, bool BC = false>
 void launch_pp(const GemmArgs& a, hipStream_t s) {
@@ -526,13 +527,14 @@ bool gemm_pp_supports(const GemmArgs& a, int epi) {
     if (!(epi == EPI_STORE_H16 || epi == EPI_GELU || epi == EPI_GELU_BWD || epi == EPI_STORE_F32 || epi == EPI_NONE || epi == EPI_RESID_H16)) return false;
     // measured (tools/gemm_pp_check.py, MI355X): ahead of gemm256 by 7 - 12 % on the plain 16-bit-store shapes with K <= 2304
     // (qkv forward, o / qkv dgrad), level at K = 3072, behind on the GELU epilogues (4 helper waves carry the erf VALU)
-    if (g_pp_mode == 2 && !((epi == EPI_STORE_H16 || epi == EPI_RESID_H16) && a.K1 <= 2304)) return false;
+    if (g_pp_mode == 2 && !((epi == EPI_STORE_H16 || epi == EPI_RESID_H16) && a.K1 <= g_pp_max_k)) return false;
     return shape_ok(a);
 }
 
 int gemm_pp_init() {
     g_pp_attr_err = 0;
     if (const char* e = getenv("VITLORA_GEMM_PP")) g_pp_mode = atoi(e);
+    if (const char* e = getenv("VITLORA_GEMM_PP_MAXK")) g_pp_max_k = atoi(e);
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_pp_cus = prop.multiProcessorCount;

@@ -868,7 +868,7 @@ __global__ __launch_bounds__(64) void win16_fwd_kernel(const h16* __restrict__ q
 constexpr int PLD = 64;                  // row stride of the P / dS images ([q][key] h16)
 // LDS per wave: Q, K, dO tiles (V is only ever read as row fragments: straight from global memory) + the P and dS images
 // = 28 KiB; the kernel runs one wave per SIMD (its registers: 64 of prefetch, 52 of bias), four workgroups per CU
-__global__ __launch_bounds__(64) void win16_bwd_kernel(const h16* __restrict__ qkv, int ldq, const float* __restrict__ table,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void win16_bwd_kernel(const h16* __restrict__ qkv, int ldq, const float* __restrict__ table,
                                                        const h16* __restrict__ dctx, int ldc, const float* __restrict__ lse,
                                                        h16* __restrict__ dqkv, int B, int H, int W, int C, int heads,
                                                        int shift, int64_t items) {
@@ -1026,6 +1026,7 @@ __global__ __launch_bounds__(64) void win16_bwd_kernel(const h16* __restrict__ q
 }
 
 // persistent grid of the window kernels: `per_cu` single-wave workgroups per CU, a multiple of `heads`, at most one per item
+int g_win_bwd_per_cu = 5;    // VITLORA_SWIN_WIN_BWD: single-wave workgroups of the backward window kernel per CU (LDS: 28 KB each -> 5; registers: 2 per SIMD since round 5)
 int g_win_cus = 256;       // VITLORA_SWIN_WIN_CUS: CUs a window-attention launch is sized for (A/B knob: half the chip per chain when two chains run)
 inline unsigned win16_grid(int64_t items, int heads, int per_cu) {
     int64_t wn = (int64_t)g_win_cus * per_cu / heads * heads;
@@ -1118,6 +1119,7 @@ struct vl_swin {
     // (shared weights) whose workspace pointers are carved into the SAME planned bytes as the main workspace (never live together).
     static constexpr int MAXCH = 4;
     vl_swin* chain[MAXCH] = {nullptr, nullptr, nullptr, nullptr};
+    int chain_offset = 0;
     int chain_batch = 0, chains_on = 2, chain_min = 32;      // VITLORA_SWIN_CHAINS = number of chains (0 / 1: off, default 2, at most 4); VITLORA_SWIN_CHAIN_MIN: smallest batch that is split
     hipStream_t side[MAXCH - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -1339,7 +1341,7 @@ void swin16_block_bwd(vl_swin* m, SStage& st, SBlock& bk, int B, int shift, hipS
     lin16_dgrad(m, st, bk.o, st.gh16, st.LC, Mp, M, g, EPI_STORE_H16, s);
     const int64_t witems = (int64_t)B * nW * st.heads;
     if (g_poison_lds) vl_poison_lds(s);      // test hook (prof.h): the window kernels keep K / V / Q / dO of a window in LDS
-    hipLaunchKernelGGL(win16_bwd_kernel, dim3(win16_grid(witems, st.heads, 4)), dim3(64), 0, s,
+    hipLaunchKernelGGL(win16_bwd_kernel, dim3(win16_grid(witems, st.heads, g_win_bwd_per_cu)), dim3(64), 0, s,
                        bk.qkv16, st.L3, bk.table, st.dctx16, st.LD, bk.lse, st.dqkv16, B, Hs, Hs, Cs, st.heads, shift, witems);
     memset(&g, 0, sizeof g); g.C = st.dh16; g.ldc = st.LD;
     lin16_dgrad(m, st, bk.qkv, st.dqkv16, st.L3, Mp, M, g, EPI_STORE_H16, s);
@@ -1391,7 +1393,9 @@ int vl_swin_create(const vl_swin_config* cfg, vl_swin** out) {
     if (const char* mf = getenv("VITLORA_SWIN_MLP_FUSED")) m->mlp_fused = atoi(mf);
     if (const char* ch = getenv("VITLORA_SWIN_CHAINS")) m->chains_on = std::min(atoi(ch), (int)vl_swin::MAXCH);
     if (const char* cm = getenv("VITLORA_SWIN_CHAIN_MIN")) m->chain_min = atoi(cm);
+    if (const char* co = getenv("VITLORA_SWIN_CHAIN_OFFSET")) m->chain_offset = atoi(co);
     if (const char* wc = getenv("VITLORA_SWIN_WIN_CUS")) g_win_cus = atoi(wc);
+    if (const char* wb = getenv("VITLORA_SWIN_WIN_BWD")) g_win_bwd_per_cu = atoi(wb);
     if (const char* fm = getenv("VITLORA_SWIN_FUSE_MERGE")) m->fuse_merge = fm[0] != '0';
     m->S = cfg->image_size; m->P = cfg->patch_size; m->G0 = m->S / m->P; m->E = cfg->embed_dim; m->C = cfg->num_labels;
     m->r = cfg->lora_targets ? cfg->lora_r : 0;
@@ -1995,14 +1999,23 @@ int vl_swin_pgd_attack(vl_swin* m, const float* x0, const int64_t* labels, int b
         else if (adv_out != x0) HIPCHK(hipMemcpyAsync(adv_out, x0, n * sizeof(float), hipMemcpyDeviceToDevice, s));
         for (int c = 0; c < NC; ++c)
             HIPCHK(hipMemcpyAsync(m->chain[c]->stage_adv, adv_out + first[c] * img, (size_t)bsz[c] * img * sizeof(float), hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipEventRecord(m->ev_fork, s));
-        for (int c = 1; c < NC; ++c) HIPCHK(hipStreamWaitEvent(m->side[c - 1], m->ev_fork, 0));
+        // chain_offset: the other chains start when chain 0 has finished its FIRST forward, so that from then on one chain is in the
+        // MFMA / latency-bound half of a step while the other is in the VALU / HBM-bound half (VITLORA_SWIN_CHAIN_OFFSET)
+        const bool offset = m->chain_offset != 0;
+        if (!offset) {
+            HIPCHK(hipEventRecord(m->ev_fork, s));
+            for (int c = 1; c < NC; ++c) HIPCHK(hipStreamWaitEvent(m->side[c - 1], m->ev_fork, 0));
+        }
         for (int i = 0; i < steps; ++i)
             for (int c = 0; c < NC; ++c) {
                 vl_swin* ch = m->chain[c];
                 hipStream_t sc = c ? m->side[c - 1] : s;
                 const int64_t nc = (int64_t)bsz[c] * img;
                 if ((rc = swin_forward(ch, ch->stage_adv, bsz[c], 1, sc))) return rc;
+                if (offset && i == 0 && c == 0) {
+                    HIPCHK(hipEventRecord(m->ev_fork, s));
+                    for (int k = 1; k < NC; ++k) HIPCHK(hipStreamWaitEvent(m->side[k - 1], m->ev_fork, 0));
+                }
                 k_ce_loss(ch->logits, ch->stage_labels, bsz[c], ch->C, ch->dlogits, ch->loss_img, ch->loss, ch->err_flag, sc);
                 ch->have_loss = 1;
                 if ((rc = swin_backward(ch, ch->grad_img, sc))) return rc;
