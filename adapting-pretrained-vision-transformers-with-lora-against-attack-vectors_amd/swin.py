@@ -45,8 +45,9 @@ class SwinArch:
 class SwinEngine:
     def __init__(self, arch: Optional[SwinArch] = None, lora_r: int = 0, lora_alpha: float = 16.0, lora_targets=(), device="cuda:0",
                  precision: str = "f32"):
-        """precision: "f32" (every operand fp32, exact-f32 MFMA) or "f16" (blocks on h16 operands with fp32 accumulation and an
-        fp32 residual stream, windowed attention on the 16x16x32 MFMA; patch embedding, patch merging and the head stay fp32)."""
+        """precision: "f32" (every operand fp32, exact-f32 MFMA) or "f16" (h16 operands with fp32 accumulation, h16 residual stream
+        and gradient stream, windowed attention on the 16x16x32 MFMA, 16-bit patch embedding and patch merging; LayerNorm statistics,
+        the mean-pool head and the classifier stay fp32; `pgd_attack` runs batches of >= 32 images as two half-batch chains)."""
         if precision not in ("f32", "f16"):
             raise ValueError("precision must be 'f32' or 'f16'")
         self.precision = precision
