@@ -394,6 +394,10 @@ bool plan_tiles(int M, int N, int G, int* nbig, int* nsmall) {
     return ok;
 }
 
+int g_tail_sibling = 0;                 // VITLORA_TAIL_SIBLING=1 / 2: tail launch as a parallel graph branch (2: enqueued before the main launch)
+hipStream_t g_tail_stream = nullptr;
+hipEvent_t g_tail_fork = nullptr, g_tail_join = nullptr;
+
 template <int BM, int EPI>
 void launch_one(const GemmArgs& a, int ntiles, int bm0, hipStream_t s) {
     if (ntiles <= 0) return;
@@ -421,6 +425,18 @@ void launch_t(const GemmArgs& a, hipStream_t s) {
     }
     int nbig = 0, nsmall = 0;
     plan_tiles(a.M, a.N, g_num_cus, &nbig, &nsmall);
+    if (g_tail_sibling && nbig > 0 && nsmall > 0 && g_tail_stream && !g_prof) {
+        // A/B (round-4 verdict 1a): the 128-row tail as a SIBLING of the main launch -- a parallel branch on a second stream
+        // between a fork and a join -- instead of its successor (the rows are disjoint)
+        (void)hipEventRecord(g_tail_fork, s);
+        (void)hipStreamWaitEvent(g_tail_stream, g_tail_fork, 0);
+        if (g_tail_sibling == 2) launch_one<128, EPI>(a, nsmall, (nbig / (a.N / BN)) * 2, g_tail_stream);      // tail enqueued first
+        launch_one<256, EPI>(a, nbig, 0, s);
+        if (g_tail_sibling != 2) launch_one<128, EPI>(a, nsmall, (nbig / (a.N / BN)) * 2, g_tail_stream);
+        (void)hipEventRecord(g_tail_join, g_tail_stream);
+        (void)hipStreamWaitEvent(s, g_tail_join, 0);
+        return;
+    }
     launch_one<256, EPI>(a, nbig, 0, s);
     launch_one<128, EPI>(a, nsmall, (nbig / (a.N / BN)) * 2, s);
 }
@@ -452,6 +468,11 @@ void gemm256_set_cus(int n) { g_num_cus = n; }
 int gemm256_init() {
     g_attr_err256 = 0;
     if (const char* tc = getenv("VITLORA_TAIL_COST")) g_tail_cost = atof(tc);
+    if (const char* ts = getenv("VITLORA_TAIL_SIBLING")) g_tail_sibling = atoi(ts);
+    if (g_tail_sibling && !g_tail_stream) {
+        if (hipStreamCreateWithFlags(&g_tail_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&g_tail_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g_tail_join, hipEventDisableTiming) != hipSuccess) { g_tail_stream = nullptr; g_tail_sibling = 0; }
+    }
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
